@@ -1,0 +1,128 @@
+/* lama_hip.h -- C ABI of liblama_hip.so: the MI355X (gfx950) kernels behind the LaMa FFC generator.
+ *
+ * The reference (advimman/lama) has no FFI: its hot path is Python calling PyTorch ops.  This header
+ * is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md).  Each entry point
+ * names the reference code whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = LAMA_ERR_* (bad argument / unsupported shape),
+ *     >0 = hipError_t of the failing runtime call.  Nothing throws, exits or synchronises the host.
+ *   - all pointers are DEVICE pointers owned by the caller (inputs, outputs, packed weights and
+ *     workspace).  The library allocates nothing and keeps no state; every launch is asynchronous on
+ *     the given hipStream_t (passed as void*) and is hipGraph-capturable.
+ *   - activations are fp32 NCHW "views": element (b,c,y,x) of a lama_tensor lives at
+ *     ptr[b*batch_stride + (c*H + y)*W + x]; batch_stride lets a view address a channel slice of a
+ *     wider buffer (the bottleneck state keeps x_l | x_g in one 512-channel buffer, which makes
+ *     ConcatTupleLayer, ffc.py:295-302, free).
+ */
+#ifndef LAMA_HIP_H
+#define LAMA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAMA_HIP_VERSION 100
+
+#define LAMA_OK 0
+#define LAMA_ERR_BAD_ARG (-1)
+#define LAMA_ERR_UNSUPPORTED (-2)
+#define LAMA_ERR_WORKSPACE (-3)
+
+/* activation applied in a conv epilogue */
+#define LAMA_ACT_NONE 0
+#define LAMA_ACT_RELU 1
+#define LAMA_ACT_SIGMOID 2
+#define LAMA_ACT_TANH 3
+
+/* padding mode of a conv */
+#define LAMA_PAD_ZERO 0
+#define LAMA_PAD_REFLECT 1
+
+/* arithmetic of the MFMA contraction */
+#define LAMA_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain)          */
+#define LAMA_PREC_BF16X3 1 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_bf16 */
+
+typedef struct lama_tensor {
+    void* ptr;            /* device pointer to element (0,0,0,0) of the view; NULL = absent          */
+    int64_t batch_stride; /* elements between consecutive images                                     */
+    int32_t C, H, W;
+} lama_tensor;
+
+/* One fused convolution launch:
+ *     y = act( conv(x, w) [+ conv1x1(x2, w2)] + bias ) [+ resid]
+ * Replaces nn.Conv2d(padding_mode='reflect') + BatchNorm2d(eval) + ReLU (+ residual add) chains:
+ *   - FFC.convl2l/convl2g/convg2l 3x3 reflect convs, ffc.py:188-196, 220-223
+ *   - FFC_BN_ACT bn_l/bn_g + act, ffc.py:251-255 (BN scale folded into w at pack time, shift = bias)
+ *   - SpectralTransform.conv1 / conv2 and FourierUnit.conv_layer 1x1 convs, ffc.py:57-59,128-140
+ *   - FFCResnetBlock residual add, ffc.py:288 (resid)
+ *   - stem 7x7 / stride-2 downsamples / ConvTranspose2d upsamples / 7x7 head + sigmoid,
+ *     ffc.py:315-363 (transposed = 1 means ConvTranspose2d(k3,s2,p1,op1))
+ * x2/w2: optional second operand contracted with a 1x1 kernel into the same accumulator
+ *        (out_xg = convl2g(x_l) + convg2g.conv2(t), ffc.py:161,223 in one pass).
+ */
+typedef struct lama_conv2d_args {
+    lama_tensor x;
+    const void* w_packed; /* from lama_conv2d_pack_weight                                  */
+    int32_t kh, kw, stride, pad, pad_mode, transposed;
+    lama_tensor x2;
+    const void* w2_packed;
+    const float* bias; /* [Cout] or NULL                                                 */
+    int32_t act;
+    lama_tensor resid; /* added after the activation; ptr NULL = none                    */
+    lama_tensor y;
+    int32_t batch;
+    int32_t precision; /* LAMA_PREC_*                                                    */
+} lama_conv2d_args;
+
+int lama_version(void);
+const char* lama_error_string(int code);
+
+/* Packed-weight size in BYTES for a conv with the given geometry. */
+int64_t lama_conv2d_packed_weight_bytes(int32_t cout, int32_t cin, int32_t kh, int32_t kw, int32_t stride,
+                                        int32_t transposed, int32_t precision);
+/* Repack reference-layout weights (Conv2d: [Cout,Cin,kh,kw]; ConvTranspose2d: [Cin,Cout,kh,kw], both
+ * as stored in the checkpoint) into the kernel's K-major layout, multiplying
+ * output channel o by scale[o] (folded BatchNorm gamma/sqrt(var+eps); NULL = 1). */
+int lama_conv2d_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t kh,
+                            int32_t kw, int32_t stride, int32_t transposed, int32_t precision, void* dst);
+int lama_conv2d_fwd(void* stream, const lama_conv2d_args* args);
+
+/* torch.fft.rfftn(x, dim=(-2,-1), norm='ortho') followed by the Re/Im channel interleave
+ * (ffc.py:86-89): x [B,C,h,w] -> spec [B,2C,h,w/2+1], channel 2c = Re, 2c+1 = Im. */
+int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch, void* workspace,
+                   size_t workspace_bytes);
+/* de-interleave + torch.fft.irfftn(s=(h,w), dim=(-2,-1), norm='ortho') on a NON-Hermitian spectrum
+ * (ffc.py:103-108; complex inverse along h, then c2r along w ignoring Im of bins 0 and w/2), fused
+ * with the `x + fu(x)` add of SpectralTransform.forward (ffc.py:161): y = resid + irfft2(spec).
+ * resid may be absent.  y [B,C,h,w]. */
+int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* y,
+                    int32_t batch, void* workspace, size_t workspace_bytes);
+/* scratch bytes lama_rfft2_fwd / lama_irfft2_fwd / lama_fourier_unit_fwd need for [B,C,h,w] */
+size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w);
+
+/* FourierUnit.forward (ffc.py:76-113) in one call: y = [x +] irfft2( relu( W' rfft2(x) + b ) ).
+ * w_packed = lama_conv2d_pack_weight(conv_layer.weight [2C,2C,1,1], bn scale); bias = bn shift.
+ * workspace >= lama_fourier_unit_workspace_bytes. add_input != 0 fuses SpectralTransform's x + fu(x). */
+size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w);
+int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
+                          const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision, void* workspace,
+                          size_t workspace_bytes);
+
+/* masked_img = cat(img*(1-mask), mask), trainers/default.py:59,67-68.  img [B,3,H,W], mask [B,1,H,W] -> out [B,4,H,W] */
+int lama_mask_compose_fwd(void* stream, const lama_tensor* image, const lama_tensor* mask, const lama_tensor* out,
+                          int32_t batch);
+/* inpainted = mask*pred + (1-mask)*img, trainers/default.py:71 */
+int lama_blend_fwd(void* stream, const lama_tensor* image, const lama_tensor* mask, const lama_tensor* pred,
+                   const lama_tensor* out, int32_t batch);
+/* np.clip(x*255, 0, 255).astype(uint8) of the HWC-permuted, cropped result, bin/predict.py:86-92.
+ * src [B,3,H,W] fp32 -> dst u8 [B, crop_h, crop_w, 3] (RGB). */
+int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, uint8_t* dst, int32_t batch, int32_t crop_h,
+                             int32_t crop_w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMA_HIP_H */

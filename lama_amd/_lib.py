@@ -1,0 +1,181 @@
+"""ctypes binding of the C ABI declared in include/lama_hip.h.
+
+``LamaLib()`` loads the in-tree ``lama_amd/lib/liblama_hip.so`` (built by ``lama_amd.build`` /
+``__graft_entry__.build()``) and raises if it is missing: there is no CPU or eager-PyTorch fallback.
+All entry points take raw device pointers (``tensor.data_ptr()``) and a ``hipStream_t``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+PREC_F32, PREC_BF16X3 = 0, 1
+
+_DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
+
+
+class LamaError(RuntimeError):
+    pass
+
+
+class Tensor4(C.Structure):
+    """struct lama_tensor"""
+    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32)]
+
+
+class Conv2dArgs(C.Structure):
+    """struct lama_conv2d_args"""
+    _fields_ = [('x', Tensor4), ('w_packed', C.c_void_p),
+                ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+                ('pad_mode', C.c_int32), ('transposed', C.c_int32),
+                ('x2', Tensor4), ('w2_packed', C.c_void_p), ('bias', C.c_void_p), ('act', C.c_int32),
+                ('resid', Tensor4), ('y', Tensor4), ('batch', C.c_int32), ('precision', C.c_int32)]
+
+
+def view(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Tensor4:
+    """lama_tensor view of channels [c0, c0+c) of a contiguous fp32 NCHW tensor (None -> absent)."""
+    if t is None:
+        return Tensor4(None, 0, 0, 0, 0)
+    if t.dtype != torch.float32 or t.dim() != 4 or not t.is_contiguous():
+        raise LamaError(f'expected a contiguous fp32 NCHW tensor, got {t.dtype} {tuple(t.shape)}')
+    B, Ct, H, W = t.shape
+    c = Ct - c0 if c is None else c
+    if c0 < 0 or c <= 0 or c0 + c > Ct:
+        raise LamaError('channel slice out of range')
+    return Tensor4(t.data_ptr() + 4 * c0 * H * W, Ct * H * W, c, H, W)
+
+
+class LamaLib:
+    def __init__(self, path: Optional[str] = None):
+        path = path or _DEFAULT
+        if not os.path.exists(path):
+            raise LamaError(f'{path} not found: build it with `python -m lama_amd.build` '
+                            f'(hipcc --offload-arch=gfx950); lama_amd has no fallback path')
+        self.path = path
+        L = self._l = C.CDLL(path)
+        i32, i64, vp, sz = C.c_int32, C.c_int64, C.c_void_p, C.c_size_t
+        T = C.POINTER(Tensor4)
+        L.lama_version.restype = C.c_int
+        L.lama_error_string.restype = C.c_char_p
+        L.lama_error_string.argtypes = [C.c_int]
+        L.lama_conv2d_packed_weight_bytes.restype = i64
+        L.lama_conv2d_packed_weight_bytes.argtypes = [i32] * 7
+        L.lama_conv2d_pack_weight.restype = C.c_int
+        L.lama_conv2d_pack_weight.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
+        L.lama_conv2d_fwd.restype = C.c_int
+        L.lama_conv2d_fwd.argtypes = [vp, C.POINTER(Conv2dArgs)]
+        L.lama_rfft2_fwd.restype = C.c_int
+        L.lama_rfft2_fwd.argtypes = [vp, T, T, i32, vp, sz]
+        L.lama_irfft2_fwd.restype = C.c_int
+        L.lama_irfft2_fwd.argtypes = [vp, T, T, T, i32, vp, sz]
+        L.lama_fft_workspace_bytes.restype = sz
+        L.lama_fft_workspace_bytes.argtypes = [i32] * 4
+        L.lama_fourier_unit_workspace_bytes.restype = sz
+        L.lama_fourier_unit_workspace_bytes.argtypes = [i32] * 4
+        L.lama_fourier_unit_fwd.restype = C.c_int
+        L.lama_fourier_unit_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz]
+        L.lama_mask_compose_fwd.restype = C.c_int
+        L.lama_mask_compose_fwd.argtypes = [vp, T, T, T, i32]
+        L.lama_blend_fwd.restype = C.c_int
+        L.lama_blend_fwd.argtypes = [vp, T, T, T, T, i32]
+        L.lama_quantize_u8_hwc_fwd.restype = C.c_int
+        L.lama_quantize_u8_hwc_fwd.argtypes = [vp, T, vp, i32, i32, i32]
+        if L.lama_version() != 100:
+            raise LamaError(f'{path}: ABI version {L.lama_version()} != 100')
+
+    # -- helpers -------------------------------------------------------------------------------
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise LamaError(f'{what} failed: {self._l.lama_error_string(rc).decode()} (code {rc})')
+
+    @staticmethod
+    def stream_of(t: torch.Tensor) -> int:
+        return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+    # -- conv ------------------------------------------------------------------------------------
+    def pack_conv_weight(self, w: torch.Tensor, scale: Optional[torch.Tensor], stride: int = 1, transposed: bool = False,
+                         precision: int = PREC_F32) -> torch.Tensor:
+        """Reference-layout conv weight (+ folded BN scale) -> packed device buffer."""
+        w = w.contiguous().float()
+        if transposed:
+            cin, cout, kh, kw = w.shape
+        else:
+            cout, cin, kh, kw = w.shape
+        nbytes = self._l.lama_conv2d_packed_weight_bytes(cout, cin, kh, kw, stride, int(transposed), precision)
+        if nbytes <= 0:
+            raise LamaError(f'unsupported conv geometry {tuple(w.shape)} stride={stride} transposed={transposed}')
+        dst = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        sc = None if scale is None else scale.contiguous().float().to(w.device)
+        self.check(self._l.lama_conv2d_pack_weight(self.stream_of(w), w.data_ptr(), None if sc is None else sc.data_ptr(),
+                                                   cout, cin, kh, kw, stride, int(transposed), precision, dst.data_ptr()),
+                   'lama_conv2d_pack_weight')
+        if w.is_cuda:
+            torch.cuda.current_stream(w.device).synchronize()  # w / sc may be temporaries
+        return dst
+
+    def conv2d(self, x: Tensor4, w_packed: torch.Tensor, y: Tensor4, batch: int, k: int, stride: int = 1, pad: int = 0,
+               pad_mode: int = PAD_REFLECT, transposed: bool = False, bias: Optional[torch.Tensor] = None,
+               act: int = ACT_NONE, resid: Optional[Tensor4] = None, x2: Optional[Tensor4] = None,
+               w2_packed: Optional[torch.Tensor] = None, precision: int = PREC_F32, stream: int = 0):
+        a = Conv2dArgs()
+        a.x, a.w_packed = x, w_packed.data_ptr()
+        a.kh = a.kw = k
+        a.stride, a.pad, a.pad_mode, a.transposed = stride, pad, pad_mode, int(transposed)
+        if x2 is not None:
+            a.x2, a.w2_packed = x2, w2_packed.data_ptr()
+        a.bias = None if bias is None else bias.data_ptr()
+        a.act = act
+        if resid is not None:
+            a.resid = resid
+        a.y, a.batch, a.precision = y, batch, precision
+        self.check(self._l.lama_conv2d_fwd(stream, C.byref(a)), 'lama_conv2d_fwd')
+
+    # -- fft -------------------------------------------------------------------------------------
+    def fft_workspace_bytes(self, b, c, h, w) -> int:
+        return int(self._l.lama_fft_workspace_bytes(b, c, h, w))
+
+    def rfft2(self, x: Tensor4, spec: Tensor4, batch: int, ws: Optional[torch.Tensor] = None, stream: int = 0):
+        self.check(self._l.lama_rfft2_fwd(stream, C.byref(x), C.byref(spec), batch,
+                                          None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * ws.element_size()),
+                   'lama_rfft2_fwd')
+
+    def irfft2(self, spec: Tensor4, resid: Optional[Tensor4], y: Tensor4, batch: int, ws: Optional[torch.Tensor] = None,
+               stream: int = 0):
+        self.check(self._l.lama_irfft2_fwd(stream, C.byref(spec), None if resid is None else C.byref(resid), C.byref(y), batch,
+                                           None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * ws.element_size()),
+                   'lama_irfft2_fwd')
+
+    def fourier_unit_workspace_bytes(self, b, c, h, w) -> int:
+        return int(self._l.lama_fourier_unit_workspace_bytes(b, c, h, w))
+
+    def fourier_unit(self, x: Tensor4, w_packed: torch.Tensor, bias: torch.Tensor, y: Tensor4, batch: int, add_input: bool,
+                     ws: torch.Tensor, precision: int = PREC_F32, stream: int = 0):
+        self.check(self._l.lama_fourier_unit_fwd(stream, C.byref(x), w_packed.data_ptr(), bias.data_ptr(), C.byref(y), batch,
+                                                 int(add_input), precision, ws.data_ptr(), ws.numel() * ws.element_size()),
+                   'lama_fourier_unit_fwd')
+
+    # -- elementwise -------------------------------------------------------------------------------
+    def mask_compose(self, image: Tensor4, mask: Tensor4, out: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_mask_compose_fwd(stream, C.byref(image), C.byref(mask), C.byref(out), batch), 'lama_mask_compose_fwd')
+
+    def blend(self, image: Tensor4, mask: Tensor4, pred: Tensor4, out: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_blend_fwd(stream, C.byref(image), C.byref(mask), C.byref(pred), C.byref(out), batch), 'lama_blend_fwd')
+
+    def quantize_u8_hwc(self, src: Tensor4, dst: torch.Tensor, batch: int, crop_h: int, crop_w: int, stream: int = 0):
+        self.check(self._l.lama_quantize_u8_hwc_fwd(stream, C.byref(src), dst.data_ptr(), batch, crop_h, crop_w), 'lama_quantize_u8_hwc_fwd')
+
+
+_LIB: Optional[LamaLib] = None
+
+
+def get_lib() -> LamaLib:
+    """The process-wide HIP library (loaded on first use; raises LamaError if it was not built)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = LamaLib()
+    return _LIB

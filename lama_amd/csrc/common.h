@@ -1,0 +1,35 @@
+// Shared declarations for the gfx950 kernels of liblama_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "lama_hip.h"
+
+#define LAMA_NTHREADS 256
+
+// All LDS lives in the dynamic region (16-byte aligned base, no static __shared__ in front of it).
+extern __shared__ __attribute__((aligned(16))) char lama_smem[];
+
+#define LAMA_CHECK_LAUNCH()                      \
+    do {                                         \
+        hipError_t e__ = hipGetLastError();      \
+        if (e__ != hipSuccess) return (int)e__;  \
+    } while (0)
+
+static inline int lama_ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t lama_ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int lama_round_up(int a, int b) { return lama_ceil_div(a, b) * b; }
+static inline bool lama_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+static inline int lama_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// XCD-aware remap of the linear workgroup id: hardware places block i on XCD i % 8; give every XCD a
+// contiguous range of logical ids so neighbouring tiles (shared input patches / weights) hit one L2.
+// Bijective for any grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").
+__device__ __forceinline__ int lama_xcd_remap(int orig, int nwg) {
+    int xcd = orig & 7, idx = orig >> 3;
+    int q = nwg >> 3, r = nwg & 7;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}

@@ -1,0 +1,177 @@
+// Elementwise pre/post kernels of the inference path, the composite FourierUnit entry point and the
+// misc C-ABI functions.
+#include "common.h"
+
+struct EwParams {
+    const float* img;
+    long long img_bs;
+    const float* mask;
+    long long mask_bs;
+    const float* pred;
+    long long pred_bs;
+    float* out;
+    long long out_bs;
+    long long hw;
+    int B;
+};
+
+// masked_img = cat(img*(1-mask), mask)  (trainers/default.py:59,67-68)
+__global__ __launch_bounds__(LAMA_NTHREADS) void mask_compose_kernel(EwParams p) {
+    long long total = (long long)p.B * p.hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)(i / p.hw);
+        long long px = i - (long long)b * p.hw;
+        float m = p.mask[b * p.mask_bs + px];
+        const float* im = p.img + b * p.img_bs + px;
+        float* o = p.out + b * p.out_bs + px;
+        float k = 1.0f - m;
+        o[0] = im[0] * k;
+        o[p.hw] = im[p.hw] * k;
+        o[2 * p.hw] = im[2 * p.hw] * k;
+        o[3 * p.hw] = m;
+    }
+}
+
+// inpainted = mask*pred + (1-mask)*img  (trainers/default.py:71)
+__global__ __launch_bounds__(LAMA_NTHREADS) void blend_kernel(EwParams p) {
+    long long total = (long long)p.B * p.hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)(i / p.hw);
+        long long px = i - (long long)b * p.hw;
+        float m = p.mask[b * p.mask_bs + px];
+        float k = 1.0f - m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            p.out[b * p.out_bs + c * p.hw + px] = m * p.pred[b * p.pred_bs + c * p.hw + px] + k * p.img[b * p.img_bs + c * p.hw + px];
+    }
+}
+
+struct QuantParams {
+    const float* src;
+    long long src_bs;
+    uint8_t* dst;
+    int B, H, W, ch, cw;
+};
+
+// np.clip(x*255, 0, 255).astype('uint8') (truncation) of x.permute(1,2,0)[:ch,:cw]  (bin/predict.py:86-92)
+__global__ __launch_bounds__(LAMA_NTHREADS) void quantize_u8_hwc_kernel(QuantParams p) {
+    long long total = (long long)p.B * p.ch * p.cw * 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int c = (int)(i % 3);
+        long long r = i / 3;
+        int x = (int)(r % p.cw);
+        r /= p.cw;
+        int y = (int)(r % p.ch);
+        int b = (int)(r / p.ch);
+        float v = p.src[b * p.src_bs + ((long long)c * p.H + y) * p.W + x] * 255.0f;
+        v = fminf(fmaxf(v, 0.0f), 255.0f);
+        p.dst[i] = (uint8_t)v;
+    }
+}
+
+namespace {
+int ew_grid(long long total) {
+    long long g = (total + LAMA_NTHREADS - 1) / LAMA_NTHREADS;
+    return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+bool same_hw(const lama_tensor* a, const lama_tensor* b) { return a->H == b->H && a->W == b->W; }
+}  // namespace
+
+extern "C" int lama_version(void) { return LAMA_HIP_VERSION; }
+
+extern "C" const char* lama_error_string(int code) {
+    switch (code) {
+        case LAMA_OK: return "ok";
+        case LAMA_ERR_BAD_ARG: return "bad argument";
+        case LAMA_ERR_UNSUPPORTED: return "unsupported shape or option";
+        case LAMA_ERR_WORKSPACE: return "workspace missing or too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+extern "C" int lama_mask_compose_fwd(void* stream, const lama_tensor* image, const lama_tensor* mask,
+                                     const lama_tensor* out, int32_t batch) {
+    if (!image || !mask || !out || !image->ptr || !mask->ptr || !out->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (image->C != 3 || mask->C != 1 || out->C != 4 || !same_hw(image, mask) || !same_hw(image, out)) return LAMA_ERR_BAD_ARG;
+    EwParams p;
+    memset(&p, 0, sizeof(p));
+    p.img = (const float*)image->ptr; p.img_bs = image->batch_stride;
+    p.mask = (const float*)mask->ptr; p.mask_bs = mask->batch_stride;
+    p.out = (float*)out->ptr; p.out_bs = out->batch_stride;
+    p.hw = (long long)image->H * image->W;
+    p.B = batch;
+    hipLaunchKernelGGL(mask_compose_kernel, dim3(ew_grid(p.B * p.hw)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+extern "C" int lama_blend_fwd(void* stream, const lama_tensor* image, const lama_tensor* mask, const lama_tensor* pred,
+                              const lama_tensor* out, int32_t batch) {
+    if (!image || !mask || !pred || !out || !image->ptr || !mask->ptr || !pred->ptr || !out->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (image->C != 3 || mask->C != 1 || pred->C != 3 || out->C != 3) return LAMA_ERR_BAD_ARG;
+    if (!same_hw(image, mask) || !same_hw(image, pred) || !same_hw(image, out)) return LAMA_ERR_BAD_ARG;
+    EwParams p;
+    memset(&p, 0, sizeof(p));
+    p.img = (const float*)image->ptr; p.img_bs = image->batch_stride;
+    p.mask = (const float*)mask->ptr; p.mask_bs = mask->batch_stride;
+    p.pred = (const float*)pred->ptr; p.pred_bs = pred->batch_stride;
+    p.out = (float*)out->ptr; p.out_bs = out->batch_stride;
+    p.hw = (long long)image->H * image->W;
+    p.B = batch;
+    hipLaunchKernelGGL(blend_kernel, dim3(ew_grid(p.B * p.hw)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+extern "C" int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, uint8_t* dst, int32_t batch,
+                                        int32_t crop_h, int32_t crop_w) {
+    if (!src || !src->ptr || !dst || batch <= 0 || src->C != 3) return LAMA_ERR_BAD_ARG;
+    if (crop_h <= 0 || crop_w <= 0 || crop_h > src->H || crop_w > src->W) return LAMA_ERR_BAD_ARG;
+    QuantParams p;
+    p.src = (const float*)src->ptr; p.src_bs = src->batch_stride;
+    p.dst = dst;
+    p.B = batch; p.H = src->H; p.W = src->W; p.ch = crop_h; p.cw = crop_w;
+    hipLaunchKernelGGL(quantize_u8_hwc_kernel, dim3(ew_grid((long long)batch * crop_h * crop_w * 3)), dim3(LAMA_NTHREADS), 0,
+                       (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+// ---- FourierUnit.forward (ffc.py:76-113) as three launches over caller workspace ------------------
+extern "C" size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w) {
+    if (batch <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    size_t spec = (size_t)batch * 2 * C * h * (w / 2 + 1) * sizeof(float);
+    spec = (spec + 255) & ~(size_t)255;
+    return 2 * spec + lama_fft_workspace_bytes(batch, C, h, w);
+}
+
+extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
+                                     const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
+                                     void* workspace, size_t workspace_bytes) {
+    if (!x || !y || !x->ptr || !y->ptr || !w_packed || batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (x->C != y->C || x->H != y->H || x->W != y->W) return LAMA_ERR_BAD_ARG;
+    const int C = x->C, h = x->H, w = x->W, wf = w / 2 + 1;
+    if (!workspace || workspace_bytes < lama_fourier_unit_workspace_bytes(batch, C, h, w)) return LAMA_ERR_WORKSPACE;
+    size_t spec_bytes = ((size_t)batch * 2 * C * h * wf * sizeof(float) + 255) & ~(size_t)255;
+    char* ws = (char*)workspace;
+    lama_tensor s1 = {ws, (int64_t)2 * C * h * wf, 2 * C, h, wf};
+    lama_tensor s2 = {ws + spec_bytes, (int64_t)2 * C * h * wf, 2 * C, h, wf};
+    void* fws = ws + 2 * spec_bytes;
+    size_t fws_bytes = workspace_bytes - 2 * spec_bytes;
+    int rc = lama_rfft2_fwd(stream, x, &s1, batch, fws, fws_bytes);
+    if (rc) return rc;
+    lama_conv2d_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = s1;
+    a.w_packed = w_packed;
+    a.kh = a.kw = 1;
+    a.stride = 1;
+    a.bias = bias;
+    a.act = LAMA_ACT_RELU;
+    a.y = s2;
+    a.batch = batch;
+    a.precision = precision;
+    rc = lama_conv2d_fwd(stream, &a);
+    if (rc) return rc;
+    return lama_irfft2_fwd(stream, &s2, add_input ? x : nullptr, y, batch, fws, fws_bytes);
+}

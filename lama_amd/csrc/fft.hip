@@ -1,0 +1,582 @@
+// Batched 2-D real FFTs of the FourierUnit (ffc.py:86-89,103-108), norm='ortho'.
+//
+//   rfft2 : x [B,C,h,w] fp32           -> spec [B,2C,h,wf]  (channel 2c = Re, 2c+1 = Im, wf = w/2+1)
+//   irfft2: spec [B,2C,h,wf] (NOT Hermitian: it went through conv+BN+ReLU) -> y = [resid +] irfftn(spec)
+//
+// The Re/Im interleave + permute + contiguous copies of the reference (ffc.py:87-89,103-105) do not
+// exist here: the forward kernel writes the two planes the spectral 1x1 GEMM reads, the inverse
+// kernel reads the two planes it wrote.
+//
+// Fast path (h, w powers of two, 16..128): one workgroup owns PPW whole planes in LDS.
+//   rows  : two real rows are transformed as ONE complex FFT (z = row_2f + i*row_2f+1) and untangled,
+//   cols  : the purely real DC and Nyquist columns are packed into ONE complex column, so a plane
+//           costs h/2 row FFTs of length w plus w/2 column FFTs of length h (both directions);
+//   passes: Stockham autosort, radix 8/4/2, ping-pong between two LDS buffers, one barrier per pass;
+//           lanes run across independent FFTs (row stride w+1 / wf float2 = odd) so every ds_read_b64 /
+//           ds_write_b64 of a pass is bank-conflict free whatever the butterfly stride;
+//   inverse: irfftn on a non-Hermitian spectrum = complex inverse along h, then c2r along w that
+//           ignores Im of bins 0 and w/2.  Re(ifft_h(col)) of those two columns equals the inverse of
+//           their Hermitian-symmetrised parts, which are packed into one complex column again.
+// Generic path (any h, w): separable direct DFT, rows and columns in two kernels through a float2
+// workspace [B*C][h][wf] (O(n) more flops; used for non power-of-two planes and planes > 128).
+#include "common.h"
+
+#define FFT_SQRT1_2 0.70710678118654752440f
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// multiply by -i (forward) or +i (inverse)
+template <bool INV>
+__device__ __forceinline__ float2 cmul_mi(float2 a) { return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x); }
+
+template <bool INV>
+__device__ __forceinline__ void dft2(float2& a, float2& b) {
+    float2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+// natural-order 4-point DFT, in place
+template <bool INV>
+__device__ __forceinline__ void dft4(float2& u0, float2& u1, float2& u2, float2& u3) {
+    float2 c0 = cadd(u0, u2), c1 = cadd(u1, u3), d0 = csub(u0, u2), d1 = cmul_mi<INV>(csub(u1, u3));
+    u0 = cadd(c0, c1);
+    u2 = csub(c0, c1);
+    u1 = cadd(d0, d1);
+    u3 = csub(d0, d1);
+}
+// natural-order 8-point DFT, in place: X[2m] = DFT4(v[r]+v[r+4]), X[2m+1] = DFT4((v[r]-v[r+4]) W8^r)
+template <bool INV>
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+    float2 a0 = cadd(v[0], v[4]), a1 = cadd(v[1], v[5]), a2 = cadd(v[2], v[6]), a3 = cadd(v[3], v[7]);
+    float2 b0 = csub(v[0], v[4]), b1 = csub(v[1], v[5]), b2 = csub(v[2], v[6]), b3 = csub(v[3], v[7]);
+    const float s = FFT_SQRT1_2;
+    // W8^1 = (s, -s) fwd / (s, +s) inv ; W8^2 = -i / +i ; W8^3 = (-s, -s) fwd / (-s, +s) inv
+    b1 = INV ? make_float2(s * (b1.x - b1.y), s * (b1.x + b1.y)) : make_float2(s * (b1.x + b1.y), s * (b1.y - b1.x));
+    b2 = cmul_mi<INV>(b2);
+    b3 = INV ? make_float2(-s * (b3.x + b3.y), s * (b3.x - b3.y)) : make_float2(s * (b3.y - b3.x), -s * (b3.x + b3.y));
+    dft4<INV>(a0, a1, a2, a3);
+    dft4<INV>(b0, b1, b2, b3);
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+    v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+
+// One Stockham pass of radix R over `nfft` length-N FFTs living in LDS.
+//   element j of FFT f: src[f*fstride + j*estride]; tw[m] = exp(-/+ 2 pi i m / N).
+//   out[(j/Ns)*Ns*R + (j%Ns) + r*Ns] = sum_r' in[j + r'*N/R] * w^(r'*(j%Ns)) * W_R^(r r')
+template <int R, bool INV>
+__device__ __forceinline__ void fft_pass(const float2* src, float2* dst, const float2* tw, int N, int Ns, int nfft,
+                                         int estride, int fstride, int ninner, int ostride) {
+    const int nb = N / R;
+    const int items = nfft * nb;
+    const int twstep = N / (Ns * R);
+    for (int item = threadIdx.x; item < items; item += LAMA_NTHREADS) {
+        int f = item % nfft, j = item / nfft;
+        int k = j & (Ns - 1);
+        int fo = f / ninner;
+        const int fbase = fo * ostride + (f - fo * ninner) * fstride;  // FFT f = (outer fo, inner fi)
+        const float2* s = src + fbase;
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = s[(j + r * nb) * estride];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * k * twstep]);
+        }
+        if constexpr (R == 8) {
+            dft8<INV>(v);
+        } else if constexpr (R == 4) {
+            dft4<INV>(v[0], v[1], v[2], v[3]);
+        } else {
+            dft2<INV>(v[0], v[1]);
+        }
+        float2* d = dst + fbase;
+        int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) d[(j0 + r * Ns) * estride] = v[r];
+    }
+}
+
+// Full FFT of length N (power of two >= 2) over nfft sequences; ping-pongs between bufA (input) and
+// bufB, returns the buffer holding the result.  Ends with a barrier.
+template <bool INV>
+__device__ __forceinline__ float2* fft_lds(float2* bufA, float2* bufB, const float2* tw, int N, int nfft, int estride,
+                                           int fstride, int ninner, int ostride) {
+    float2* src = bufA;
+    float2* dst = bufB;
+    int Ns = 1;
+    while (Ns < N) {
+        int rem = N / Ns;
+        if (rem >= 8) {
+            fft_pass<8, INV>(src, dst, tw, N, Ns, nfft, estride, fstride, ninner, ostride);
+            Ns *= 8;
+        } else if (rem == 4) {
+            fft_pass<4, INV>(src, dst, tw, N, Ns, nfft, estride, fstride, ninner, ostride);
+            Ns *= 4;
+        } else {
+            fft_pass<2, INV>(src, dst, tw, N, Ns, nfft, estride, fstride, ninner, ostride);
+            Ns *= 2;
+        }
+        __syncthreads();
+        float2* t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+struct FftParams {
+    const float* x;      // forward: input planes; inverse: residual (may be null)
+    long long x_bstride;
+    float* spec;         // forward: output; inverse: input
+    long long spec_bstride;
+    float* y;            // inverse output
+    long long y_bstride;
+    int C, h, w, wf;
+    int nplanes;         // B*C
+    int ppw;             // planes per workgroup
+    float scale;         // 1/sqrt(h*w)
+};
+
+template <bool INV>
+__device__ __forceinline__ void fft_init_twiddles(float2* tw, int N) {
+    for (int m = threadIdx.x; m < N; m += LAMA_NTHREADS) {
+        double s, c;
+        sincospi(2.0 * (double)m / (double)N, &s, &c);
+        tw[m] = make_float2((float)c, INV ? (float)s : (float)(-s));
+    }
+}
+
+// lane -> (f, q) map for the row-pair load/store: 16 consecutive lanes = 4 float4 columns x 4 row pairs,
+// which makes the ds_write_b64/ds_read_b64 of the interleaved (row 2f, row 2f+1) float2 conflict free.
+__device__ __forceinline__ void rowpair_item(int item, int wq, int& f, int& q) {
+    int q_lo = item & 3, f_lo = (item >> 2) & 3, rest = item >> 4;
+    int wq4 = wq >> 2;  // w/16
+    int q_hi = rest % wq4, f_hi = rest / wq4;
+    q = q_hi * 4 + q_lo;
+    f = f_hi * 4 + f_lo;
+}
+
+__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
+    const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
+    const int RSW = w + 1;
+    const int bufsz = p.ppw * (hh * RSW > h * wf ? hh * RSW : h * wf);
+    float2* tww = reinterpret_cast<float2*>(lama_smem);
+    float2* twh = tww + w;
+    float2* P = twh + h;
+    float2* Q = P + bufsz;
+    const int tid = threadIdx.x;
+    const int plane0 = blockIdx.x * p.ppw;
+    const int np = (p.nplanes - plane0) < p.ppw ? (p.nplanes - plane0) : p.ppw;
+
+    fft_init_twiddles<false>(tww, w);
+    fft_init_twiddles<false>(twh, h);
+    // 1. load row pairs: P[pl][f][n] = (x[2f][n], x[2f+1][n])
+    {
+        const int wq = w >> 2;
+        const int per_plane = hh * wq;
+        for (int item = tid; item < np * per_plane; item += LAMA_NTHREADS) {
+            int pl = item / per_plane, f, q;
+            rowpair_item(item - pl * per_plane, wq, f, q);
+            int plane = plane0 + pl;
+            int b = plane / p.C, c = plane - b * p.C;
+            const float* src = p.x + (long long)b * p.x_bstride + (long long)c * h * w + (2 * f) * w + q * 4;
+            float4 ra = *reinterpret_cast<const float4*>(src);
+            float4 rb = *reinterpret_cast<const float4*>(src + w);
+            float2* d = P + (pl * hh + f) * RSW + q * 4;
+            d[0] = make_float2(ra.x, rb.x);
+            d[1] = make_float2(ra.y, rb.y);
+            d[2] = make_float2(ra.z, rb.z);
+            d[3] = make_float2(ra.w, rb.w);
+        }
+    }
+    __syncthreads();
+    // 2. row FFTs (length w) of the packed row pairs
+    float2* E1 = fft_lds<false>(P, Q, tww, w, np * hh, 1, RSW, np * hh, 0);
+    float2* S = (E1 == P) ? Q : P;  // spectrum buffer, [pl][h][wf]
+    // 3. untangle the pairs into the half spectra of the two rows; column 0 packs (DC, Nyquist)
+    for (int item = tid; item < np * hh * wh; item += LAMA_NTHREADS) {
+        int fg = item % (np * hh), k = item / (np * hh);
+        int pl = fg / hh, f = fg - pl * hh;
+        const float2* z = E1 + fg * RSW;
+        float2* sa = S + (pl * h + 2 * f) * wf;
+        float2* sb = sa + wf;
+        if (k == 0) {
+            float2 z0 = z[0], zn = z[wh];
+            sa[0] = make_float2(z0.x, zn.x);
+            sb[0] = make_float2(z0.y, zn.y);
+        } else {
+            float2 zk = z[k], zm = z[w - k];
+            sa[k] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            sb[k] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        }
+    }
+    __syncthreads();
+    // 4. column FFTs (length h) over columns 0..w/2-1 of every plane
+    //    FFT index = (plane, column): inner stride 1 (column), outer stride h*wf (plane)
+    float2* E2 = fft_lds<false>(S, E1, twh, h, np * wh, wf, 1, wh, h * wf);
+    // 5. untangle column 0 into the DC (col 0) and Nyquist (col w/2) columns
+    {
+        float2 x0 = make_float2(0.f, 0.f), xn = x0;
+        const bool act = tid < np * h;
+        int pl = tid / h, k = tid - pl * h;
+        if (act) {
+            float2 c = E2[(pl * h + k) * wf], cm = E2[(pl * h + ((h - k) & (h - 1))) * wf];
+            x0 = make_float2(0.5f * (c.x + cm.x), 0.5f * (c.y - cm.y));
+            xn = make_float2(0.5f * (c.y + cm.y), 0.5f * (cm.x - c.x));
+        }
+        __syncthreads();
+        if (act) {
+            E2[(pl * h + k) * wf] = x0;
+            E2[(pl * h + k) * wf + wh] = xn;
+        }
+    }
+    __syncthreads();
+    // 6. store the Re / Im planes (channels 2c, 2c+1), ortho scale
+    {
+        const int per_plane = h * wf;
+        for (int item = tid; item < np * per_plane; item += LAMA_NTHREADS) {
+            int pl = item / per_plane, i = item - pl * per_plane;
+            int plane = plane0 + pl;
+            int b = plane / p.C, c = plane - b * p.C;
+            float2 v = E2[pl * per_plane + i];
+            float* dst = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
+            dst[0] = v.x * p.scale;
+            dst[per_plane] = v.y * p.scale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) {
+    const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
+    const int RSW = w + 1;
+    const int bufsz = p.ppw * (hh * RSW > h * wf ? hh * RSW : h * wf);
+    float2* tww = reinterpret_cast<float2*>(lama_smem);
+    float2* twh = tww + w;
+    float2* P = twh + h;
+    float2* Q = P + bufsz;
+    const int tid = threadIdx.x;
+    const int plane0 = blockIdx.x * p.ppw;
+    const int np = (p.nplanes - plane0) < p.ppw ? (p.nplanes - plane0) : p.ppw;
+    const int per_plane = h * wf;
+
+    fft_init_twiddles<true>(tww, w);
+    fft_init_twiddles<true>(twh, h);
+    // 1. load the Re / Im planes: P[pl][u][k]
+    for (int item = tid; item < np * per_plane; item += LAMA_NTHREADS) {
+        int pl = item / per_plane, i = item - pl * per_plane;
+        int plane = plane0 + pl;
+        int b = plane / p.C, c = plane - b * p.C;
+        const float* src = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
+        P[pl * per_plane + i] = make_float2(src[0], src[per_plane]);
+    }
+    __syncthreads();
+    // 2. Hermitian-symmetrise columns 0 and w/2 along h and pack them into column 0:
+    //    G = D_h + i E_h,  D_h[u] = (D[u] + conj(D[-u]))/2  (so that ifft_h(G) = Re z0 + i Re z_{w/2})
+    {
+        float2 g = make_float2(0.f, 0.f);
+        const bool act = tid < np * h;
+        int pl = tid / h, u = tid - pl * h;
+        if (act) {
+            const float2* r0 = P + (pl * h + u) * wf;
+            const float2* r1 = P + (pl * h + ((h - u) & (h - 1))) * wf;
+            float2 d = r0[0], dm = r1[0], e = r0[wh], em = r1[wh];
+            float2 dh = make_float2(0.5f * (d.x + dm.x), 0.5f * (d.y - dm.y));
+            float2 eh = make_float2(0.5f * (e.x + em.x), 0.5f * (e.y - em.y));
+            g = make_float2(dh.x - eh.y, dh.y + eh.x);
+        }
+        __syncthreads();
+        if (act) P[(pl * h + u) * wf] = g;
+    }
+    __syncthreads();
+    // 3. inverse column FFTs (length h) over columns 0..w/2-1
+    float2* E1 = fft_lds<true>(P, Q, twh, h, np * wh, wf, 1, wh, per_plane);
+    float2* Z = (E1 == P) ? Q : P;  // row-pair buffer [pl][hh][RSW]
+    // 4. build the Hermitian-extended row pairs: W[k] = Za[k] + i Zb[k], W[w-k] = conj(Za[k]) + i conj(Zb[k])
+    for (int item = tid; item < np * hh * wh; item += LAMA_NTHREADS) {
+        int fg = item % (np * hh), k = item / (np * hh);
+        int pl = fg / hh, f = fg - pl * hh;
+        const float2* sa = E1 + (pl * h + 2 * f) * wf;
+        const float2* sb = sa + wf;
+        float2* z = Z + fg * RSW;
+        float2 za = sa[k], zb = sb[k];
+        if (k == 0) {
+            z[0] = make_float2(za.x, zb.x);
+            z[wh] = make_float2(za.y, zb.y);
+        } else {
+            z[k] = make_float2(za.x - zb.y, za.y + zb.x);
+            z[w - k] = make_float2(za.x + zb.y, zb.x - za.y);
+        }
+    }
+    __syncthreads();
+    // 5. inverse row FFTs (length w)
+    float2* O = E1;
+    float2* E2 = fft_lds<true>(Z, O, tww, w, np * hh, 1, RSW, np * hh, 0);
+    // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
+    {
+        const int wq = w >> 2;
+        const int pp = hh * wq;
+        for (int item = tid; item < np * pp; item += LAMA_NTHREADS) {
+            int pl = item / pp, f, q;
+            rowpair_item(item - pl * pp, wq, f, q);
+            int plane = plane0 + pl;
+            int b = plane / p.C, c = plane - b * p.C;
+            const float2* s = E2 + (pl * hh + f) * RSW + q * 4;
+            float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+            long long off = (long long)c * h * w + (2 * f) * w + q * 4;
+            float4 ra = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
+            float4 rb = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
+            if (p.x) {
+                const float* r = p.x + (long long)b * p.x_bstride + off;
+                float4 xa = *reinterpret_cast<const float4*>(r);
+                float4 xb = *reinterpret_cast<const float4*>(r + w);
+                ra.x += xa.x; ra.y += xa.y; ra.z += xa.z; ra.w += xa.w;
+                rb.x += xb.x; rb.y += xb.y; rb.z += xb.z; rb.w += xb.w;
+            }
+            float* d = p.y + (long long)b * p.y_bstride + off;
+            *reinterpret_cast<float4*>(d) = ra;
+            *reinterpret_cast<float4*>(d + w) = rb;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic path: separable direct DFT through a float2 workspace ws[plane][h][wf]
+// ------------------------------------------------------------------------------------------------
+#define DFT_ROWS_PER_WG 8
+#define DFT_COLS_PER_WG 8
+
+// forward rows: ws[plane][y][k] = sum_n x[y][n] e^{-2 pi i n k / w}
+__global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_fwd_kernel(FftParams p, float2* ws) {
+    const int w = p.w, wf = p.wf, h = p.h;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float* rows = reinterpret_cast<float*>(tw + w);
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * DFT_ROWS_PER_WG;
+    const long long nrows = (long long)p.nplanes * h;
+    fft_init_twiddles<false>(tw, w);
+    for (int i = tid; i < DFT_ROWS_PER_WG * w; i += LAMA_NTHREADS) {
+        int r = i / w, n = i - r * w;
+        long long row = row0 + r;
+        float v = 0.f;
+        if (row < nrows) {
+            int plane = (int)(row / h), y = (int)(row - (long long)plane * h);
+            int b = plane / p.C, c = plane - b * p.C;
+            v = p.x[(long long)b * p.x_bstride + ((long long)c * h + y) * w + n];
+        }
+        rows[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < DFT_ROWS_PER_WG * wf; i += LAMA_NTHREADS) {
+        int r = i / wf, k = i - r * wf;
+        long long row = row0 + r;
+        if (row >= nrows) continue;
+        const float* xr = rows + r * w;
+        float ar = 0.f, ai = 0.f;
+        int idx = 0;
+        for (int n = 0; n < w; ++n) {
+            float2 t = tw[idx];
+            ar += xr[n] * t.x;
+            ai += xr[n] * t.y;
+            idx += k;
+            if (idx >= w) idx -= w;
+        }
+        ws[row * wf + k] = make_float2(ar, ai);
+    }
+}
+
+// forward columns: spec[u][k] = scale * sum_y ws[y][k] e^{-2 pi i y u / h}; inverse columns (INV):
+// ws_out[y][k] = sum_u spec[u][k] e^{+2 pi i u y / h}
+template <bool INV>
+__global__ __launch_bounds__(LAMA_NTHREADS) void dft_cols_kernel(FftParams p, float2* ws) {
+    const int wf = p.wf, h = p.h;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* cols = tw + h;  // [h][DFT_COLS_PER_WG]
+    const int tid = threadIdx.x;
+    const int ncb = (wf + DFT_COLS_PER_WG - 1) / DFT_COLS_PER_WG;
+    const int plane = blockIdx.x / ncb, k0 = (blockIdx.x - plane * ncb) * DFT_COLS_PER_WG;
+    const int b = plane / p.C, c = plane - b * p.C;
+    const long long per_plane = (long long)h * wf;
+    float* sre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    float* sim = sre + per_plane;
+    fft_init_twiddles<INV>(tw, h);
+    for (int i = tid; i < h * DFT_COLS_PER_WG; i += LAMA_NTHREADS) {
+        int y = i / DFT_COLS_PER_WG, kk = i - y * DFT_COLS_PER_WG;
+        int k = k0 + kk;
+        float2 v = make_float2(0.f, 0.f);
+        if (k < wf) v = INV ? make_float2(sre[(long long)y * wf + k], sim[(long long)y * wf + k]) : ws[(long long)plane * per_plane + (long long)y * wf + k];
+        cols[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < h * DFT_COLS_PER_WG; i += LAMA_NTHREADS) {
+        int u = i / DFT_COLS_PER_WG, kk = i - u * DFT_COLS_PER_WG;
+        int k = k0 + kk;
+        if (k >= wf) continue;
+        float ar = 0.f, ai = 0.f;
+        int idx = 0;
+        for (int y = 0; y < h; ++y) {
+            float2 t = tw[idx], v = cols[y * DFT_COLS_PER_WG + kk];
+            ar += v.x * t.x - v.y * t.y;
+            ai += v.x * t.y + v.y * t.x;
+            idx += u;
+            if (idx >= h) idx -= h;
+        }
+        if (INV) {
+            ws[(long long)plane * per_plane + (long long)u * wf + k] = make_float2(ar, ai);
+        } else {
+            sre[(long long)u * wf + k] = ar * p.scale;
+            sim[(long long)u * wf + k] = ai * p.scale;
+        }
+    }
+}
+
+// inverse rows (c2r ignoring Im of bins 0 and w/2): y[x] = scale*(Re z0 + (-1)^x Re z_{w/2} + 2 sum Re(z_k e^{2 pi i k x/w})) + resid
+__global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_inv_kernel(FftParams p, const float2* ws) {
+    const int w = p.w, wf = p.wf, h = p.h;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* rows = tw + w;  // [ROWS][wf]
+    const int tid = threadIdx.x;
+    const long long row0 = (long long)blockIdx.x * DFT_ROWS_PER_WG;
+    const long long nrows = (long long)p.nplanes * h;
+    fft_init_twiddles<true>(tw, w);
+    for (int i = tid; i < DFT_ROWS_PER_WG * wf; i += LAMA_NTHREADS) {
+        int r = i / wf;
+        long long row = row0 + r;
+        rows[i] = row < nrows ? ws[row * wf + (i - r * wf)] : make_float2(0.f, 0.f);
+    }
+    __syncthreads();
+    const int kmax = (w & 1) ? wf - 1 : wf - 2;  // last bin that has a conjugate partner
+    for (int i = tid; i < DFT_ROWS_PER_WG * w; i += LAMA_NTHREADS) {
+        int r = i / w, xx = i - r * w;
+        long long row = row0 + r;
+        if (row >= nrows) continue;
+        const float2* z = rows + r * wf;
+        float acc = z[0].x;
+        if (!(w & 1)) acc += (xx & 1) ? -z[wf - 1].x : z[wf - 1].x;
+        float s2 = 0.f;
+        int idx = 0;
+        for (int k = 1; k <= kmax; ++k) {
+            idx += xx;
+            if (idx >= w) idx -= w;
+            float2 t = tw[idx];
+            s2 += z[k].x * t.x - z[k].y * t.y;
+        }
+        acc = (acc + 2.0f * s2) * p.scale;
+        int plane = (int)(row / h), y = (int)(row - (long long)plane * h);
+        int b = plane / p.C, c = plane - b * p.C;
+        long long off = ((long long)c * h + y) * w + xx;
+        if (p.x) acc += p.x[(long long)b * p.x_bstride + off];
+        p.y[(long long)b * p.y_bstride + off] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+bool fft_fast_ok(int h, int w) { return lama_is_pow2(h) && lama_is_pow2(w) && h >= 16 && w >= 16 && h <= 128 && w <= 128; }
+
+int fft_ppw(int h, int w) {
+    // planes per workgroup: keep ~256 butterflies per pass busy, LDS <= 64 KiB
+    int ppw = 1;
+    while (ppw < 16 && (ppw * 2) * (h / 2) * (w / 8) <= 256 && (ppw * 2) * h <= 256) ppw *= 2;
+    return ppw;
+}
+
+size_t fft_lds_bytes(int h, int w, int ppw) {
+    int wf = w / 2 + 1, hh = h / 2, RSW = w + 1;
+    size_t buf = (size_t)ppw * (hh * RSW > h * wf ? hh * RSW : h * wf);
+    return ((size_t)w + h + 2 * buf) * sizeof(float2);
+}
+
+bool fft_args_ok(const lama_tensor* real, const lama_tensor* spec, int batch) {
+    if (!real || !spec || !real->ptr || !spec->ptr || batch <= 0) return false;
+    if (real->C <= 0 || real->H <= 0 || real->W <= 0) return false;
+    if (spec->C != 2 * real->C || spec->H != real->H || spec->W != real->W / 2 + 1) return false;
+    if (real->batch_stride < (int64_t)real->C * real->H * real->W) return false;
+    if (spec->batch_stride < (int64_t)spec->C * spec->H * spec->W) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w) {
+    if (batch <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    if (fft_fast_ok(h, w)) return 0;
+    return (size_t)batch * C * h * (w / 2 + 1) * sizeof(float2);
+}
+
+extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch,
+                              void* workspace, size_t workspace_bytes) {
+    if (!fft_args_ok(x, spec, batch)) return LAMA_ERR_BAD_ARG;
+    FftParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = (const float*)x->ptr;
+    p.x_bstride = x->batch_stride;
+    p.spec = (float*)spec->ptr;
+    p.spec_bstride = spec->batch_stride;
+    p.C = x->C; p.h = x->H; p.w = x->W; p.wf = x->W / 2 + 1;
+    p.nplanes = batch * x->C;
+    p.scale = (float)(1.0 / sqrt((double)p.h * (double)p.w));
+    hipStream_t st = (hipStream_t)stream;
+    if (fft_fast_ok(p.h, p.w) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4)) & 15) == 0) {
+        p.ppw = fft_ppw(p.h, p.w);
+        size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
+        hipLaunchKernelGGL(rfft2_lds_kernel, dim3(lama_ceil_div(p.nplanes, p.ppw)), dim3(LAMA_NTHREADS), lds, st, p);
+        LAMA_CHECK_LAUNCH();
+        return LAMA_OK;
+    }
+    size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
+    if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
+    float2* ws = (float2*)workspace;
+    long long nrows = (long long)p.nplanes * p.h;
+    size_t lds1 = (size_t)p.w * sizeof(float2) + (size_t)DFT_ROWS_PER_WG * p.w * sizeof(float);
+    size_t lds2 = (size_t)p.h * sizeof(float2) * (1 + DFT_COLS_PER_WG);
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(dft_rows_fwd_kernel, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, ws);
+    LAMA_CHECK_LAUNCH();
+    int ncb = lama_ceil_div(p.wf, DFT_COLS_PER_WG);
+    hipLaunchKernelGGL(dft_cols_kernel<false>, dim3(p.nplanes * ncb), dim3(LAMA_NTHREADS), lds2, st, p, ws);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* y,
+                               int32_t batch, void* workspace, size_t workspace_bytes) {
+    if (!fft_args_ok(y, spec, batch)) return LAMA_ERR_BAD_ARG;
+    const bool has_r = resid && resid->ptr;
+    if (has_r && (resid->C != y->C || resid->H != y->H || resid->W != y->W)) return LAMA_ERR_BAD_ARG;
+    FftParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = has_r ? (const float*)resid->ptr : nullptr;
+    p.x_bstride = has_r ? resid->batch_stride : 0;
+    p.spec = (float*)spec->ptr;
+    p.spec_bstride = spec->batch_stride;
+    p.y = (float*)y->ptr;
+    p.y_bstride = y->batch_stride;
+    p.C = y->C; p.h = y->H; p.w = y->W; p.wf = y->W / 2 + 1;
+    p.nplanes = batch * y->C;
+    p.scale = (float)(1.0 / sqrt((double)p.h * (double)p.w));
+    hipStream_t st = (hipStream_t)stream;
+    uintptr_t al = (uintptr_t)y->ptr | (uintptr_t)(y->batch_stride * 4);
+    if (has_r) al |= (uintptr_t)resid->ptr | (uintptr_t)(resid->batch_stride * 4);
+    if (fft_fast_ok(p.h, p.w) && (al & 15) == 0) {
+        p.ppw = fft_ppw(p.h, p.w);
+        size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
+        hipLaunchKernelGGL(irfft2_lds_kernel, dim3(lama_ceil_div(p.nplanes, p.ppw)), dim3(LAMA_NTHREADS), lds, st, p);
+        LAMA_CHECK_LAUNCH();
+        return LAMA_OK;
+    }
+    size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
+    if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
+    float2* ws = (float2*)workspace;
+    long long nrows = (long long)p.nplanes * p.h;
+    size_t lds1 = (size_t)p.w * sizeof(float2) + (size_t)DFT_ROWS_PER_WG * p.wf * sizeof(float2);
+    size_t lds2 = (size_t)p.h * sizeof(float2) * (1 + DFT_COLS_PER_WG);
+    if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
+    int ncb = lama_ceil_div(p.wf, DFT_COLS_PER_WG);
+    hipLaunchKernelGGL(dft_cols_kernel<true>, dim3(p.nplanes * ncb), dim3(LAMA_NTHREADS), lds2, st, p, ws);
+    LAMA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dft_rows_inv_kernel, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, (const float2*)ws);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}

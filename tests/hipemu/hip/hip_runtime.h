@@ -1,0 +1,227 @@
+// hipemu -- a tiny host-side SIMT emulator used ONLY by the CPU test-suite (tests/).
+//
+// The GPU-less build container cannot run gfx950 code, so tests compile the *unmodified* kernel
+// sources in lama_amd/csrc/ a second time with the host compiler and `-I tests/hipemu`, which makes
+// `#include <hip/hip_runtime.h>` resolve to this file.  Every thread of a workgroup runs as a
+// ucontext fiber; __syncthreads(), wave shuffles and the MFMA builtins are implemented with
+// counting barriers across fibers, so index arithmetic, LDS layouts, MFMA fragment maps and
+// barrier placement of the real kernels are exercised bit-for-bit in program order.
+// It is not a performance tool and never ships: lama_amd/ does not reference it.
+//
+// MFMA fragment maps follow /opt/skills/guides/cdna_hip_programming.md section 3:
+//   32x32x2 f32 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D col=l&31, row=(r&3)+8*(r>>2)+4*(l>>5)
+//   32x32x16 bf16: A row i=l&31, k=8*(l>>5)+e ; B col j=l&31, k=8*(l>>5)+e ; same D map.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __restrict__ __restrict
+
+namespace hipemu {
+
+struct Block;
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    dim3 tid;
+    int linear = 0;
+    bool done = false;
+    unsigned xcount = 0;  // wave-exchange counter (parity selects the deposit buffer)
+};
+struct Wave {
+    int nlanes = 0, alive = 0, count = 0, gen = 0;
+    // deposit buffers for cross-lane ops: [parity][lane][up to 16 dwords]
+    uint32_t buf[2][64][16];
+};
+struct Block {
+    dim3 bid, bdim, gdim;
+    int nthreads = 0, alive = 0, count = 0, gen = 0;
+    std::vector<Fiber> fibers;
+    std::vector<Wave> waves;
+    ucontext_t sched;
+    Fiber* cur = nullptr;
+    std::function<void()> body;
+};
+extern Block* g_blk;
+void yield();
+void block_barrier();
+void wave_barrier();
+void run_grid(dim3 grid, dim3 block, std::function<void()> body);
+inline Fiber* cur() { return g_blk->cur; }
+inline Wave& cur_wave() { return g_blk->waves[g_blk->cur->linear / 64]; }
+inline int lane() { return g_blk->cur->linear % 64; }
+
+// all lanes deposit `n` dwords, synchronise, and get a pointer to the wave's deposits
+inline uint32_t (*exchange(const uint32_t* mine, int n))[16] {
+    Fiber* f = cur();
+    Wave& w = cur_wave();
+    int par = f->xcount & 1;
+    f->xcount++;
+    for (int i = 0; i < n; ++i) w.buf[par][lane()][i] = mine[i];
+    wave_barrier();
+    return w.buf[par];
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::g_blk->cur->tid)
+#define blockIdx (hipemu::g_blk->bid)
+#define blockDim (hipemu::g_blk->bdim)
+#define gridDim (hipemu::g_blk->gdim)
+#define warpSize 64
+
+// dynamic LDS: kernels declare `extern __shared__ ... char lama_smem[];`
+extern __attribute__((aligned(16))) char lama_smem[];
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+template <class T>
+static inline T __shfl(T v, int src, int width = 64) {
+    uint32_t mine[4] = {0, 0, 0, 0};
+    static_assert(sizeof(T) <= 16, "shfl size");
+    memcpy(mine, &v, sizeof(T));
+    auto all = hipemu::exchange(mine, (sizeof(T) + 3) / 4);
+    int l = hipemu::lane();
+    int base = (l / width) * width;
+    T r;
+    memcpy(&r, all[base + (src % width + width) % width], sizeof(T));
+    return r;
+}
+template <class T>
+static inline T __shfl_xor(T v, int mask, int width = 64) { return __shfl(v, (hipemu::lane() % width) ^ mask, width); }
+template <class T>
+static inline T __shfl_down(T v, int d, int width = 64) {
+    int l = hipemu::lane() % width;
+    return __shfl(v, (l + d < width) ? l + d : l, width);
+}
+
+// ---- vector types used for MFMA fragments -------------------------------------------------
+typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+typedef short hipemu_s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 hipemu_bf16x8 __attribute__((ext_vector_type(8)));
+
+static inline float hipemu_bf16_to_f32(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c) {
+    uint32_t mine[2];
+    memcpy(&mine[0], &a, 4);
+    memcpy(&mine[1], &b, 4);
+    auto all = hipemu::exchange(mine, 2);
+    int l = hipemu::lane();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, &all[row + 32 * k][0], 4);
+            memcpy(&bv, &all[col + 32 * k][1], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+static inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c) {
+    uint32_t mine[2];
+    memcpy(&mine[0], &a, 4);
+    memcpy(&mine[1], &b, 4);
+    auto all = hipemu::exchange(mine, 2);
+    int l = hipemu::lane();
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, &all[row + 16 * k][0], 4);
+            memcpy(&bv, &all[col + 16 * k][1], 4);
+            acc = fmaf(av, bv, acc);
+        }
+        c[r] = acc;
+    }
+    return c;
+}
+// 32x32x16 bf16: operands are 8 bf16 per lane (k = 8*(l>>5)+e), fp32 accumulate.
+template <class V8>
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(V8 a, V8 b, hipemu_f32x16 c) {
+    uint32_t mine[8];
+    memcpy(&mine[0], &a, 16);
+    memcpy(&mine[4], &b, 16);
+    auto all = hipemu::exchange(mine, 8);
+    int l = hipemu::lane();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double acc = 0.0;  // products of bf16 are exact in fp32; hardware accumulates wider than fp32 chain
+        for (int kg = 0; kg < 2; ++kg) {
+            const uint16_t* ap = reinterpret_cast<const uint16_t*>(&all[row + 32 * kg][0]);
+            const uint16_t* bp = reinterpret_cast<const uint16_t*>(&all[col + 32 * kg][4]);
+            for (int e = 0; e < 8; ++e) acc += (double)hipemu_bf16_to_f32(ap[e]) * (double)hipemu_bf16_to_f32(bp[e]);
+        }
+        c[r] = (float)((double)c[r] + acc);
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_f32_32x32x2f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32_16x16x4f32(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_f32_32x32x16_bf16(a, b, c)
+
+// math helpers that exist in HIP device code
+static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
+static inline void sincospif(float x, float* s, float* c) { *s = (float)sin(M_PI * (double)x); *c = (float)cos(M_PI * (double)x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+// ---- launch --------------------------------------------------------------------------------
+template <class K, class... Args>
+static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t, Args... args) {
+    hipemu::run_grid(grid, block, [=]() { kernel(args...); });
+}

@@ -1,0 +1,178 @@
+"""CPU tests of the HIP kernel SOURCES through the host SIMT emulator (tests/hipemu): index math, LDS
+layouts, MFMA fragment maps, barrier placement and the C-ABI argument handling, checked against
+plain torch fp32 ops.  The same comparisons run on the real GPU in test_kernels_gpu.py."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lama_amd import _lib as L
+from tests.emu import emu_lib
+
+
+def _conv_ref(x, w, stride, pad, reflect, transposed, bias, act, resid, x2=None, w2=None, scale=None):
+    if scale is not None:
+        w = w * (scale[None, :, None, None] if transposed else scale[:, None, None, None])
+    if transposed:
+        y = F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1)
+    else:
+        xp = F.pad(x, (pad,) * 4, mode='reflect') if (pad and reflect) else F.pad(x, (pad,) * 4)
+        y = F.conv2d(xp, w, None, stride=stride)
+    if x2 is not None:
+        y = y + F.conv2d(x2, w2)
+    if bias is not None:
+        y = y + bias[None, :, None, None]
+    y = {0: lambda t: t, 1: torch.relu, 2: torch.sigmoid, 3: torch.tanh}[act](y)
+    if resid is not None:
+        y = y + resid
+    return y
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, reflect, transposed, H, W, act, bias, resid, scale
+    dict(cin=8, cout=16, k=3, stride=1, pad=1, H=12, W=20, act=1, bias=True, resid=True, scale=True),
+    dict(cin=12, cout=40, k=3, stride=1, pad=1, H=9, W=7, act=0, bias=False, resid=False, scale=False),
+    dict(cin=4, cout=8, k=7, stride=1, pad=3, H=16, W=24, act=1, bias=True, resid=False, scale=True),
+    dict(cin=8, cout=3, k=7, stride=1, pad=3, H=16, W=16, act=2, bias=True, resid=False, scale=False),
+    dict(cin=8, cout=16, k=3, stride=2, pad=1, H=16, W=24, act=1, bias=True, resid=False, scale=True),
+    dict(cin=6, cout=16, k=3, stride=2, pad=1, H=10, W=14, act=1, bias=True, resid=False, scale=True),
+    dict(cin=24, cout=12, k=1, stride=1, pad=0, H=6, W=11, act=1, bias=True, resid=False, scale=True),
+    dict(cin=40, cout=72, k=1, stride=1, pad=0, H=16, W=9, act=0, bias=False, resid=True, scale=False),
+    dict(cin=16, cout=8, k=3, stride=2, pad=1, H=8, W=12, act=1, bias=True, resid=False, scale=True, transposed=True),
+    dict(cin=20, cout=36, k=3, stride=2, pad=1, H=5, W=7, act=0, bias=True, resid=False, scale=False, transposed=True),
+    dict(cin=140, cout=130, k=3, stride=1, pad=1, H=8, W=8, act=1, bias=True, resid=True, scale=True),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d_emulated(case):
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(1)
+    B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
+    tr = case.get('transposed', False)
+    x = torch.randn(B, cin, case['H'], case['W'], generator=g)
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
+    bias = torch.randn(cout, generator=g) if case['bias'] else None
+    ref0 = _conv_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
+    resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
+    ref = _conv_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
+    wp = lib.pack_conv_weight(w, scale, stride=case['stride'], transposed=tr)
+    # write into a channel slice of a wider buffer to exercise the view arithmetic
+    ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0)
+    lib.conv2d(L.view(x), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'],
+               L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias, case['act'], None if resid is None else L.view(resid))
+    y = ybuf[:, 2:2 + cout]
+    assert torch.allclose(y, ref, atol=2e-4, rtol=1e-4), float((y - ref).abs().max())
+    assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0   # nothing written outside the view
+
+
+def test_conv2d_fused_second_operand_emulated():
+    """out_g = relu(convl2g(x_l) + conv2(t) + b) + resid in one launch (ffc.py:161,223,253-254,288)."""
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(2)
+    B, cl, cg, half, H, W = 2, 8, 24, 12, 10, 12
+    state = torch.randn(B, cl + cg, H, W, generator=g)
+    t = torch.randn(B, half, H, W, generator=g)
+    w1 = torch.randn(cg, cl, 3, 3, generator=g) * 0.2
+    w2 = torch.randn(cg, half, 1, 1, generator=g) * 0.2
+    scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
+    ref = _conv_ref(state[:, :cl], w1, 1, 1, True, False, bias, 1, state[:, cl:], x2=t, w2=w2 * scale[:, None, None, None], scale=scale)
+    out = torch.zeros_like(state)
+    lib.conv2d(L.view(state, 0, cl), lib.pack_conv_weight(w1, scale), L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT, False, bias,
+               L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale))
+    assert torch.allclose(out[:, cl:], ref, atol=2e-4, rtol=1e-4), float((out[:, cl:] - ref).abs().max())
+
+
+def _spec_ref(x):
+    ff = torch.fft.rfftn(x, dim=(-2, -1), norm='ortho')
+    b, c, h, wf = ff.shape
+    return torch.stack((ff.real, ff.imag), dim=2).reshape(b, 2 * c, h, wf)
+
+
+def _inv_ref(spec, h, w):
+    b, c2, _, wf = spec.shape
+    s = spec.view(b, c2 // 2, 2, h, wf)
+    return torch.fft.irfftn(torch.complex(s[:, :, 0], s[:, :, 1]), s=(h, w), dim=(-2, -1), norm='ortho')
+
+
+FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32),   # fused LDS path
+             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13)]          # generic DFT path
+
+
+@pytest.mark.parametrize('hw', FFT_SIZES, ids=lambda s: f'{s[0]}x{s[1]}')
+def test_rfft2_irfft2_emulated(hw):
+    lib = emu_lib()
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 131 + w)
+    B, Cn = 2, 3
+    wide = torch.randn(B, Cn + 2, h, w, generator=g)          # view = channels 1..Cn of a wider buffer
+    x = wide[:, 1:1 + Cn]
+    spec = torch.zeros(B, 2 * Cn, h, w // 2 + 1)
+    nws = lib.fft_workspace_bytes(B, Cn, h, w)
+    ws = torch.zeros(max(nws, 4) // 4)
+    lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, ws)
+    ref = _spec_ref(x)
+    assert torch.allclose(spec, ref, atol=3e-5, rtol=1e-4), float((spec - ref).abs().max())
+    # inverse on a NON-Hermitian spectrum (as after conv+BN+ReLU), fused residual add
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g))
+    resid = torch.randn(B, Cn, h, w, generator=g)
+    y = torch.zeros(B, Cn, h, w)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y), B, ws)
+    ref2 = resid + _inv_ref(spec2, h, w)
+    assert torch.allclose(y, ref2, atol=3e-5, rtol=1e-4), float((y - ref2).abs().max())
+    y2 = torch.zeros(B, Cn, h, w)
+    lib.irfft2(L.view(spec2), None, L.view(y2), B, ws)
+    assert torch.allclose(y2, ref2 - resid, atol=3e-5, rtol=1e-4)
+
+
+def test_fourier_unit_emulated():
+    from oracle import lama_oracle as O
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(5)
+    for (B, Cn, h, w) in [(2, 6, 16, 16), (1, 4, 10, 12)]:
+        x = torch.randn(B, Cn, h, w, generator=g)
+        sd = {'fu.conv_layer.weight': torch.randn(2 * Cn, 2 * Cn, 1, 1, generator=g) * 0.3,
+              'fu.bn.weight': torch.rand(2 * Cn, generator=g) + 0.5, 'fu.bn.bias': torch.randn(2 * Cn, generator=g) * 0.2,
+              'fu.bn.running_mean': torch.randn(2 * Cn, generator=g) * 0.1, 'fu.bn.running_var': torch.rand(2 * Cn, generator=g) + 0.5}
+        ref = O.fourier_unit(x, sd, 'fu')
+        scale = sd['fu.bn.weight'] / torch.sqrt(sd['fu.bn.running_var'] + 1e-5)
+        shift = sd['fu.bn.bias'] - sd['fu.bn.running_mean'] * scale
+        wp = lib.pack_conv_weight(sd['fu.conv_layer.weight'], scale)
+        ws = torch.zeros(lib.fourier_unit_workspace_bytes(B, Cn, h, w) // 4 + 1)
+        y = torch.zeros_like(x)
+        lib.fourier_unit(L.view(x), wp, shift, L.view(y), B, True, ws)
+        assert torch.allclose(y, x + ref, atol=1e-4, rtol=1e-4), float((y - x - ref).abs().max())
+
+
+def test_elementwise_emulated():
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 10, 14
+    img, mask = torch.rand(B, 3, H, W, generator=g), (torch.rand(B, 1, H, W, generator=g) > 0.5).float()
+    pred = torch.rand(B, 3, H, W, generator=g)
+    out = torch.zeros(B, 4, H, W)
+    lib.mask_compose(L.view(img), L.view(mask), L.view(out), B)
+    assert torch.equal(out, torch.cat([img * (1 - mask), mask], 1))
+    bl = torch.zeros(B, 3, H, W)
+    lib.blend(L.view(img), L.view(mask), L.view(pred), L.view(bl), B)
+    assert torch.allclose(bl, mask * pred + (1 - mask) * img, atol=1e-7)
+    u8 = torch.zeros(B, 7, 9, 3, dtype=torch.uint8)
+    src = torch.rand(B, 3, H, W, generator=g) * 1.2 - 0.1
+    lib.quantize_u8_hwc(L.view(src), u8, B, 7, 9)
+    ref = np.clip(src.permute(0, 2, 3, 1).numpy()[:, :7, :9] * 255, 0, 255).astype('uint8')
+    assert np.array_equal(u8.numpy(), ref)
+
+
+def test_c_abi_rejects_bad_arguments():
+    lib = emu_lib()
+    x = torch.zeros(1, 4, 8, 8)
+    with pytest.raises(L.LamaError):
+        lib.pack_conv_weight(torch.zeros(4, 4, 5, 5), None)            # unsupported kernel size
+    wp = lib.pack_conv_weight(torch.zeros(8, 4, 3, 3), None)
+    with pytest.raises(L.LamaError):
+        lib.conv2d(L.view(x), wp, L.view(torch.zeros(1, 8, 7, 8)), 1, 3, 1, 1)    # wrong output shape
+    with pytest.raises(L.LamaError):
+        lib.rfft2(L.view(x), L.view(torch.zeros(1, 8, 8, 4)), 1)      # wrong spectrum width
+    with pytest.raises(L.LamaError):
+        lib.rfft2(L.view(torch.zeros(1, 4, 10, 12)), L.view(torch.zeros(1, 8, 10, 7)), 1, None)   # missing workspace
