@@ -122,6 +122,14 @@ int lama_blend_fwd(void* stream, const lama_tensor* image, const lama_tensor* ma
 int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, uint8_t* dst, int32_t batch, int32_t crop_h,
                              int32_t crop_w);
 
+/* Stand-alone per-channel affine + activation: y = act(x*scale[c] + shift[c]) (scale/shift NULL = identity).
+ * Used when a caller runs generator.model layer by layer and hits a bare nn.BatchNorm2d (eval) /
+ * nn.ReLU / nn.Sigmoid (ffc.py:352-354,362-363); the fused forward never launches it. */
+int lama_affine_act_fwd(void* stream, const lama_tensor* x, const float* scale, const float* shift, int32_t act,
+                        const lama_tensor* y, int32_t batch);
+/* Stand-alone nn.ReflectionPad2d(pad) (ffc.py:314,360); fused into the 7x7 convs on the normal path. */
+int lama_reflect_pad_fwd(void* stream, const lama_tensor* x, int32_t pad, const lama_tensor* y, int32_t batch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,10 @@ class LamaLib:
         L.lama_blend_fwd.argtypes = [vp, T, T, T, T, i32]
         L.lama_quantize_u8_hwc_fwd.restype = C.c_int
         L.lama_quantize_u8_hwc_fwd.argtypes = [vp, T, vp, i32, i32, i32]
+        L.lama_affine_act_fwd.restype = C.c_int
+        L.lama_affine_act_fwd.argtypes = [vp, T, vp, vp, i32, T, i32]
+        L.lama_reflect_pad_fwd.restype = C.c_int
+        L.lama_reflect_pad_fwd.argtypes = [vp, T, i32, T, i32]
         if L.lama_version() != 100:
             raise LamaError(f'{path}: ABI version {L.lama_version()} != 100')
 
@@ -168,6 +172,14 @@ class LamaLib:
 
     def quantize_u8_hwc(self, src: Tensor4, dst: torch.Tensor, batch: int, crop_h: int, crop_w: int, stream: int = 0):
         self.check(self._l.lama_quantize_u8_hwc_fwd(stream, C.byref(src), dst.data_ptr(), batch, crop_h, crop_w), 'lama_quantize_u8_hwc_fwd')
+
+
+    def affine_act(self, x: Tensor4, scale, shift, act: int, y: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_affine_act_fwd(stream, C.byref(x), None if scale is None else scale.data_ptr(),
+                                               None if shift is None else shift.data_ptr(), act, C.byref(y), batch), 'lama_affine_act_fwd')
+
+    def reflect_pad(self, x: Tensor4, pad: int, y: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_reflect_pad_fwd(stream, C.byref(x), pad, C.byref(y), batch), 'lama_reflect_pad_fwd')
 
 
 _LIB: Optional[LamaLib] = None

@@ -69,6 +69,62 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void quantize_u8_hwc_kernel(QuantPar
     }
 }
 
+struct AffineParams {
+    const float* x;
+    long long x_bs;
+    const float* scale;
+    const float* shift;
+    float* y;
+    long long y_bs;
+    long long hw;
+    int C, B, act;
+};
+
+// y = act(x*scale[c] + shift[c]): stand-alone BatchNorm2d(eval) / ReLU / Sigmoid / Tanh layers
+// (generator.model[25], [26], [35] ... when a caller runs the Sequential layer by layer)
+__global__ __launch_bounds__(LAMA_NTHREADS) void affine_act_kernel(AffineParams p) {
+    long long per = (long long)p.C * p.hw, total = per * p.B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)(i / per);
+        long long r = i - (long long)b * per;
+        int c = (int)(r / p.hw);
+        float v = p.x[b * p.x_bs + r];
+        if (p.scale) v = v * p.scale[c] + p.shift[c];
+        if (p.act == LAMA_ACT_RELU) v = fmaxf(v, 0.0f);
+        else if (p.act == LAMA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+        else if (p.act == LAMA_ACT_TANH) v = tanhf(v);
+        p.y[b * p.y_bs + r] = v;
+    }
+}
+
+struct PadParams {
+    const float* x;
+    long long x_bs;
+    float* y;
+    long long y_bs;
+    int C, B, H, W, pad;
+};
+
+// nn.ReflectionPad2d(pad) as a stand-alone layer (generator.model[0], [33])
+__global__ __launch_bounds__(LAMA_NTHREADS) void reflect_pad_kernel(PadParams p) {
+    const int Ho = p.H + 2 * p.pad, Wo = p.W + 2 * p.pad;
+    long long per = (long long)p.C * Ho * Wo, total = per * p.B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int b = (int)(i / per);
+        long long r = i - (long long)b * per;
+        int xo = (int)(r % Wo);
+        long long r2 = r / Wo;
+        int yo = (int)(r2 % Ho);
+        int c = (int)(r2 / Ho);
+        int yi = yo - p.pad, xi = xo - p.pad;
+        if (yi < 0) yi = -yi;
+        if (yi >= p.H) yi = 2 * (p.H - 1) - yi;
+        if (xi < 0) xi = -xi;
+        if (xi >= p.W) xi = 2 * (p.W - 1) - xi;
+        p.y[b * p.y_bs + r] = p.x[b * p.x_bs + ((long long)c * p.H + yi) * p.W + xi];
+    }
+}
+
 namespace {
 int ew_grid(long long total) {
     long long g = (total + LAMA_NTHREADS - 1) / LAMA_NTHREADS;
@@ -133,6 +189,33 @@ extern "C" int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, ui
     p.B = batch; p.H = src->H; p.W = src->W; p.ch = crop_h; p.cw = crop_w;
     hipLaunchKernelGGL(quantize_u8_hwc_kernel, dim3(ew_grid((long long)batch * crop_h * crop_w * 3)), dim3(LAMA_NTHREADS), 0,
                        (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+extern "C" int lama_affine_act_fwd(void* stream, const lama_tensor* x, const float* scale, const float* shift, int32_t act,
+                                   const lama_tensor* y, int32_t batch) {
+    if (!x || !y || !x->ptr || !y->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (x->C != y->C || !same_hw(x, y) || ((scale == nullptr) != (shift == nullptr))) return LAMA_ERR_BAD_ARG;
+    AffineParams p;
+    p.x = (const float*)x->ptr; p.x_bs = x->batch_stride;
+    p.scale = scale; p.shift = shift;
+    p.y = (float*)y->ptr; p.y_bs = y->batch_stride;
+    p.hw = (long long)x->H * x->W;
+    p.C = x->C; p.B = batch; p.act = act;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(p.hw * p.C * p.B)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+extern "C" int lama_reflect_pad_fwd(void* stream, const lama_tensor* x, int32_t pad, const lama_tensor* y, int32_t batch) {
+    if (!x || !y || !x->ptr || !y->ptr || batch <= 0 || pad < 0) return LAMA_ERR_BAD_ARG;
+    if (x->C != y->C || y->H != x->H + 2 * pad || y->W != x->W + 2 * pad || pad >= x->H || pad >= x->W) return LAMA_ERR_BAD_ARG;
+    PadParams p;
+    p.x = (const float*)x->ptr; p.x_bs = x->batch_stride;
+    p.y = (float*)y->ptr; p.y_bs = y->batch_stride;
+    p.C = x->C; p.B = batch; p.H = x->H; p.W = x->W; p.pad = pad;
+    hipLaunchKernelGGL(reflect_pad_kernel, dim3(ew_grid((long long)batch * y->C * y->H * y->W)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }

@@ -1,0 +1,745 @@
+"""Host-side mirror of ``saicinpainting/training/modules/ffc.py`` whose forward passes run on the
+hand-written gfx950 kernels of liblama_hip.so.
+
+Same class names, constructor signatures, sub-module names and therefore the same ``state_dict`` keys
+as the reference (``generator.model.<i>....``), so a reference checkpoint loads
+with ``load_state_dict`` unchanged and ``make_generator(kind='ffc_resnet')`` can return this class.
+``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` objects are used as PARAMETER CONTAINERS
+only -- their ``forward`` is never called; all arithmetic goes through ``lama_amd._lib`` (C ABI in
+``include/lama_hip.h``).  There is no eager/CPU fallback: tensors must live on a GPU and the shared
+library must be built, otherwise ``LamaError`` is raised.
+
+Inference only (eval-mode BatchNorm folded into the conv weights; reference ffc.py:60-61,101,
+130-133,236-239,253-254).  Options no shipped config enables (LFU, SE, gates, spectral positional
+encoding, spatial scaling, 3-D FFC, groups != 1, spatial-transform wrappers, out_ffc) raise
+``NotImplementedError`` at construction.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from ._lib import LamaError
+
+_ACT = {'relu': L.ACT_RELU, 'sigmoid': L.ACT_SIGMOID, 'tanh': L.ACT_TANH, None: L.ACT_NONE}
+
+
+# ----------------------------------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------------------------------
+
+def _bn_fold(bn: nn.BatchNorm2d) -> Tuple[torch.Tensor, torch.Tensor]:
+    """eval-mode BatchNorm as y = x*scale + shift (SURVEY.md Appendix A folding recipe)."""
+    scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.detach().float() * scale
+    return scale, shift
+
+
+def _act_code(layer) -> int:
+    if layer is None or isinstance(layer, nn.Identity) or layer is nn.Identity:
+        return L.ACT_NONE
+    if isinstance(layer, nn.ReLU) or layer is nn.ReLU:
+        return L.ACT_RELU
+    if isinstance(layer, nn.Sigmoid) or layer is nn.Sigmoid:
+        return L.ACT_SIGMOID
+    if isinstance(layer, nn.Tanh) or layer is nn.Tanh:
+        return L.ACT_TANH
+    raise NotImplementedError(f'activation {layer} is not supported by the HIP epilogues')
+
+
+def _adjacent(a: torch.Tensor, b: torch.Tensor) -> Optional[torch.Tensor]:
+    """If a and b are channel slices [0:ca] and [ca:ca+cb] of ONE contiguous NCHW buffer, return that
+    buffer as a [B, ca+cb, H, W] tensor (zero-copy), else None."""
+    if a.dim() != 4 or b.dim() != 4 or a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+        return None
+    B, ca, H, W = a.shape
+    cb = b.shape[1]
+    bs = (ca + cb) * H * W
+    want = (bs, H * W, W, 1)
+    if tuple(a.stride()) != want or tuple(b.stride()) != want:
+        return None
+    if a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr():
+        return None
+    if b.storage_offset() != a.storage_offset() + ca * H * W:
+        return None
+    return torch.as_strided(a, (B, ca + cb, H, W), want, a.storage_offset())
+
+
+def _pair_buffer(x_l: torch.Tensor, x_g) -> Tuple[torch.Tensor, int, int]:
+    """(buffer [B, cl+cg, H, W], cl, cg) holding x_l | x_g channel-contiguously."""
+    if not torch.is_tensor(x_g):
+        return x_l.contiguous(), x_l.shape[1], 0
+    buf = _adjacent(x_l, x_g)
+    if buf is None:
+        buf = torch.cat([x_l, x_g], dim=1)
+    return buf, x_l.shape[1], x_g.shape[1]
+
+
+def _check_input(x: torch.Tensor):
+    if not x.is_cuda:
+        raise LamaError('lama_amd runs on an MI355X only: input tensor is on ' + str(x.device) +
+                        ' (there is no CPU fallback; the CPU oracle lives in oracle/ for tests)')
+    if x.dtype != torch.float32:
+        raise LamaError(f'fp32 activations expected, got {x.dtype}')
+
+
+class _Exec:
+    """Where kernels run: the loaded library and the stream to launch on.  The default is the in-tree
+    gfx950 library on the current torch stream; tests inject the host-emulated build of the same
+    sources (tests/hipemu) to exercise this host logic without a GPU."""
+
+    def __init__(self, lib: Optional[L.LamaLib] = None):
+        self._lib = lib
+        self.injected = lib is not None
+
+    @property
+    def lib(self) -> L.LamaLib:
+        if self._lib is None:
+            self._lib = L.get_lib()
+        return self._lib
+
+    def stream(self, t: torch.Tensor) -> int:
+        return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+    def check(self, x: torch.Tensor):
+        if not self.injected:
+            _check_input(x)
+
+
+_DEFAULT_EXEC = _Exec()
+
+
+class _HipModule(nn.Module):
+    """Base: packed-weight cache that is dropped whenever parameters may have changed."""
+
+    precision = L.PREC_F32
+
+    def __init__(self):
+        super().__init__()
+        self._packed = None
+        self._exec = _DEFAULT_EXEC
+
+    def _invalidate(self):
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m._packed = None
+
+    def _apply(self, fn, *a, **kw):
+        self._invalidate()
+        return super()._apply(fn, *a, **kw)
+
+    def load_state_dict(self, *a, **kw):
+        self._invalidate()
+        return super().load_state_dict(*a, **kw)
+
+    def set_exec(self, ex: _Exec):
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m._exec = ex
+                m._packed = None
+        return self
+
+    def set_precision(self, precision: int):
+        for m in self.modules():
+            if isinstance(m, _HipModule):
+                m.precision = precision
+                m._packed = None
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError('lama_amd modules are inference-only (eval-mode BatchNorm is folded into the kernels)')
+        return super().train(False)
+
+
+# ----------------------------------------------------------------------------------------------------
+# FourierUnit / SpectralTransform
+# ----------------------------------------------------------------------------------------------------
+
+class FourierUnit(_HipModule):
+    """ffc.py:49-113.  y = irfft2(relu(bn(conv1x1(interleave(rfft2(x))))))."""
+
+    def __init__(self, in_channels, out_channels, groups=1, spatial_scale_factor=None, spatial_scale_mode='bilinear',
+                 spectral_pos_encoding=False, use_se=False, se_kwargs=None, ffc3d=False, fft_norm='ortho'):
+        super().__init__()
+        if groups != 1 or spatial_scale_factor is not None or spectral_pos_encoding or use_se or ffc3d or fft_norm != 'ortho':
+            raise NotImplementedError('FourierUnit: only the configuration used by the shipped LaMa configs is implemented '
+                                      '(groups=1, no spatial scaling / positional encoding / SE / 3-D, ortho norm)')
+        if in_channels != out_channels:
+            raise NotImplementedError('FourierUnit: in_channels != out_channels')
+        self.groups = groups
+        self.conv_layer = nn.Conv2d(in_channels * 2, out_channels * 2, kernel_size=1, stride=1, padding=0, groups=1, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels * 2)
+        self.relu = nn.ReLU(inplace=True)
+        self.fft_norm = fft_norm
+
+    def _pack(self):
+        if self._packed is None:
+            scale, shift = _bn_fold(self.bn)
+            self._packed = (self._exec.lib.pack_conv_weight(self.conv_layer.weight.detach(), scale, precision=self.precision),
+                            shift.contiguous())
+        return self._packed
+
+    def run(self, x: L.Tensor4, y: L.Tensor4, batch: int, add_input: bool, ws: torch.Tensor, stream: int):
+        wp, shift = self._pack()
+        self._exec.lib.fourier_unit(x, wp, shift, y, batch, add_input, ws, self.precision, stream)
+
+    def workspace(self, x: torch.Tensor) -> torch.Tensor:
+        b, c, h, w = x.shape
+        n = self._exec.lib.fourier_unit_workspace_bytes(b, c, h, w)
+        return torch.empty(n // 4 + 1, dtype=torch.float32, device=x.device)
+
+    def forward(self, x: torch.Tensor, add_input: bool = False) -> torch.Tensor:
+        self._exec.check(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        self.run(L.view(x), L.view(y), x.shape[0], add_input, self.workspace(x), self._exec.stream(x))
+        return y
+
+
+class SpectralTransform(_HipModule):
+    """ffc.py:116-163 with stride 1 and LFU disabled: conv2(x1 + fu(x1)), x1 = relu(bn(conv1(x)))."""
+
+    def __init__(self, in_channels, out_channels, stride=1, groups=1, enable_lfu=True, **fu_kwargs):
+        super().__init__()
+        if enable_lfu:
+            raise NotImplementedError('SpectralTransform: enable_lfu=True is not used by any shipped LaMa config')
+        if stride != 1 or groups != 1:
+            raise NotImplementedError('SpectralTransform: stride 2 / groups != 1 are not implemented')
+        self.enable_lfu = enable_lfu
+        self.stride = stride
+        self.downsample = nn.Identity()
+        self.conv1 = nn.Sequential(nn.Conv2d(in_channels, out_channels // 2, kernel_size=1, groups=groups, bias=False),
+                                   nn.BatchNorm2d(out_channels // 2), nn.ReLU(inplace=True))
+        self.fu = FourierUnit(out_channels // 2, out_channels // 2, groups, **fu_kwargs)
+        self.conv2 = nn.Conv2d(out_channels // 2, out_channels, kernel_size=1, groups=groups, bias=False)
+
+    def _pack(self, out_scale: Optional[torch.Tensor] = None):
+        """conv1 (+ its BN) and conv2; ``out_scale`` folds the enclosing FFC_BN_ACT.bn_g into conv2."""
+        if self._packed is None:
+            lib = self._exec.lib
+            s1, b1 = _bn_fold(self.conv1[1])
+            self._packed = dict(w1=lib.pack_conv_weight(self.conv1[0].weight.detach(), s1, precision=self.precision), b1=b1.contiguous(),
+                                w2=lib.pack_conv_weight(self.conv2.weight.detach(), out_scale, precision=self.precision))
+        return self._packed
+
+    def run_front(self, xg: L.Tensor4, x1: torch.Tensor, t: torch.Tensor, ws: torch.Tensor, batch: int, stream: int):
+        """x1 = relu(bn(conv1(xg))); t = x1 + fu(x1).  (conv2 is fused by the caller.)"""
+        pk = self._packed
+        self._exec.lib.conv2d(xg, pk['w1'], L.view(x1), batch, 1, bias=pk['b1'], act=L.ACT_RELU, precision=self.precision, stream=stream)
+        self.fu.run(L.view(x1), L.view(t), batch, True, ws, stream)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._exec.check(x)
+        x = x.contiguous()
+        if self._packed is None or self._packed.get('fused_scale'):
+            self._packed = None
+            self._pack(None)
+        b, _, h, w = x.shape
+        half = self.conv2.in_channels
+        x1 = torch.empty(b, half, h, w, device=x.device, dtype=torch.float32)
+        t = torch.empty_like(x1)
+        st = self._exec.stream(x)
+        self.run_front(L.view(x), x1, t, self.fu.workspace(x1), b, st)
+        y = torch.empty(b, self.conv2.out_channels, h, w, device=x.device, dtype=torch.float32)
+        self._exec.lib.conv2d(L.view(t), self._packed['w2'], L.view(y), b, 1, precision=self.precision, stream=st)
+        return y
+
+
+# ----------------------------------------------------------------------------------------------------
+# FFC / FFC_BN_ACT / FFCResnetBlock
+# ----------------------------------------------------------------------------------------------------
+
+class FFC(_HipModule):
+    """ffc.py:166-225 (parameter container; the arithmetic is launched by FFC_BN_ACT so that BatchNorm,
+    activation and the residual fuse into the conv epilogues)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, ratio_gin, ratio_gout, stride=1, padding=0, dilation=1,
+                 groups=1, bias=False, enable_lfu=True, padding_type='reflect', gated=False, **spectral_kwargs):
+        super().__init__()
+        assert stride == 1 or stride == 2, "Stride should be 1 or 2."
+        if dilation != 1 or groups != 1 or bias or gated:
+            raise NotImplementedError('FFC: dilation/groups/bias/gated variants are not used by the shipped LaMa configs')
+        if padding_type != 'reflect' and padding != 0:
+            raise NotImplementedError('FFC: only reflect padding is implemented')
+        self.stride, self.kernel_size, self.padding = stride, kernel_size, padding
+        in_cg = int(in_channels * ratio_gin)
+        in_cl = in_channels - in_cg
+        out_cg = int(out_channels * ratio_gout)
+        out_cl = out_channels - out_cg
+        self.in_cl, self.in_cg, self.out_cl, self.out_cg = in_cl, in_cg, out_cl, out_cg
+        self.ratio_gin, self.ratio_gout = ratio_gin, ratio_gout
+        self.global_in_num = in_cg
+
+        def conv(ci, co):
+            return nn.Conv2d(ci, co, kernel_size, stride, padding, dilation, groups, bias, padding_mode=padding_type)
+
+        self.convl2l = nn.Identity() if in_cl == 0 or out_cl == 0 else conv(in_cl, out_cl)
+        self.convl2g = nn.Identity() if in_cl == 0 or out_cg == 0 else conv(in_cl, out_cg)
+        self.convg2l = nn.Identity() if in_cg == 0 or out_cl == 0 else conv(in_cg, out_cl)
+        self.convg2g = nn.Identity() if in_cg == 0 or out_cg == 0 else SpectralTransform(in_cg, out_cg, stride, 1, enable_lfu,
+                                                                                         **spectral_kwargs)
+        self.gated = gated
+        self.gate = nn.Identity()
+        if in_cl == 0:
+            raise NotImplementedError('FFC with ratio_gin == 1 (no local input) is not implemented')
+        if in_cg > 0 and (out_cl == 0 or out_cg == 0):
+            raise NotImplementedError('FFC with a global input needs both local and global outputs (ratio_gout in (0,1))')
+        if in_cg > 0 and (stride != 1 or kernel_size != 3):
+            raise NotImplementedError('FFC with a global input is implemented for 3x3 stride-1 layers (the resnet blocks)')
+
+    def forward(self, x):
+        raise NotImplementedError('lama_amd.ffc.FFC is launched through FFC_BN_ACT (BatchNorm/activation are fused into its '
+                                  'kernels); call the enclosing FFC_BN_ACT instead')
+
+
+class FFC_BN_ACT(_HipModule):
+    """ffc.py:228-255: FFC + BatchNorm (local, global) + activation, as 1 launch (no global branch) or
+    6 launches (conv1x1, rfft2, spectral conv1x1, irfft2+add, fused local conv, fused global conv)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, ratio_gin, ratio_gout, stride=1, padding=0, dilation=1,
+                 groups=1, bias=False, norm_layer=nn.BatchNorm2d, activation_layer=nn.Identity, padding_type='reflect',
+                 enable_lfu=True, **kwargs):
+        super().__init__()
+        if norm_layer is not nn.BatchNorm2d:
+            raise NotImplementedError('only BatchNorm2d (eval) is folded into the kernels')
+        self.ffc = FFC(in_channels, out_channels, kernel_size, ratio_gin, ratio_gout, stride, padding, dilation, groups, bias,
+                       enable_lfu, padding_type=padding_type, **kwargs)
+        global_channels = int(out_channels * ratio_gout)
+        self.bn_l = nn.Identity() if ratio_gout == 1 else nn.BatchNorm2d(out_channels - global_channels)
+        self.bn_g = nn.Identity() if ratio_gout == 0 else nn.BatchNorm2d(global_channels)
+        self.act_l = nn.Identity() if ratio_gout == 1 else activation_layer(inplace=True)
+        self.act_g = nn.Identity() if ratio_gout == 0 else activation_layer(inplace=True)
+        self._act = _act_code(activation_layer)
+
+    # -- packing -------------------------------------------------------------------------------------
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        f, lib, prec = self.ffc, self._exec.lib, self.precision
+        pk = {}
+        sl, bl = _bn_fold(self.bn_l) if f.out_cl else (None, None)
+        sg, bg = _bn_fold(self.bn_g) if f.out_cg else (None, None)
+        if f.in_cg == 0:
+            # every output comes from x_l: ONE conv with [convl2l ; convl2g] stacked along Cout
+            ws, ss, bs = [], [], []
+            if f.out_cl:
+                ws.append(f.convl2l.weight.detach()); ss.append(sl); bs.append(bl)
+            if f.out_cg:
+                ws.append(f.convl2g.weight.detach()); ss.append(sg); bs.append(bg)
+            pk['w_all'] = lib.pack_conv_weight(torch.cat(ws, 0), torch.cat(ss, 0), stride=f.stride, precision=prec)
+            pk['b_all'] = torch.cat(bs, 0).contiguous()
+        else:
+            # local output: conv over the whole state buffer [x_l | x_g] with [convl2l , convg2l] stacked along Cin
+            w_lout = torch.cat([f.convl2l.weight.detach(), f.convg2l.weight.detach()], dim=1)
+            pk['w_lout'] = lib.pack_conv_weight(w_lout, sl, precision=prec)
+            pk['b_l'] = bl.contiguous()
+            pk['w_l2g'] = lib.pack_conv_weight(f.convl2g.weight.detach(), sg, precision=prec)
+            pk['b_g'] = bg.contiguous()
+            st = f.convg2g
+            st._packed = None
+            st._pack(sg)
+            st._packed['fused_scale'] = True
+            st.fu._pack()
+        self._packed = pk
+        return pk
+
+    # -- launch --------------------------------------------------------------------------------------
+    def run(self, src: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], resid: Optional[torch.Tensor] = None,
+            extra_pad: int = 0):
+        """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous)."""
+        f, lib, prec = self.ffc, self._exec.lib, self.precision
+        if f.in_cg and not (f.convg2g._packed or {}).get('fused_scale'):
+            self._packed = None   # a stand-alone SpectralTransform.forward re-packed conv2 without bn_g
+        pk = self._pack()
+        B = src.shape[0]
+        st = self._exec.stream(src)
+        pad = f.padding + extra_pad
+        if f.in_cg == 0:
+            lib.conv2d(L.view(src), pk['w_all'], L.view(dst), B, f.kernel_size, f.stride, pad, L.PAD_REFLECT, False, pk['b_all'],
+                       self._act, None if resid is None else L.view(resid), precision=prec, stream=st)
+            return
+        cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
+        spec = f.convg2g
+        spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st)
+        lib.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], self._act,
+                   None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+        lib.conv2d(L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], self._act,
+                   None if resid is None else L.view(resid, ocl, ocg), x2=L.view(scratch['t']), w2_packed=spec._packed['w2'],
+                   precision=prec, stream=st)
+
+    def out_shape(self, src_shape, extra_pad: int = 0):
+        f = self.ffc
+        B, _, H, W = src_shape
+        pad = f.padding + extra_pad
+        Ho = (H + 2 * pad - f.kernel_size) // f.stride + 1
+        Wo = (W + 2 * pad - f.kernel_size) // f.stride + 1
+        return (B, f.out_cl + f.out_cg, Ho, Wo)
+
+    def make_scratch(self, src_shape, device) -> Optional[dict]:
+        f = self.ffc
+        if f.in_cg == 0:
+            return None
+        B, _, H, W = src_shape
+        half = f.convg2g.conv2.in_channels
+        x1 = torch.empty(B, half, H, W, device=device, dtype=torch.float32)
+        return dict(x1=x1, t=torch.empty_like(x1), ws=f.convg2g.fu.workspace(x1))
+
+    def forward(self, x, extra_pad: int = 0):
+        x_l, x_g = x if type(x) is tuple else (x, 0)
+        self._exec.check(x_l)
+        src, cl, cg = _pair_buffer(x_l, x_g)
+        if cl != self.ffc.in_cl or cg != self.ffc.in_cg:
+            raise LamaError(f'FFC_BN_ACT expected ({self.ffc.in_cl},{self.ffc.in_cg}) local/global channels, got ({cl},{cg})')
+        dst = torch.empty(self.out_shape(src.shape, extra_pad), device=src.device, dtype=torch.float32)
+        self.run(src, dst, self.make_scratch(src.shape, src.device), None, extra_pad)
+        ocl, ocg = self.ffc.out_cl, self.ffc.out_cg
+        return (dst[:, :ocl] if ocl else 0), (dst[:, ocl:] if ocg else 0)
+
+
+class FFCResnetBlock(_HipModule):
+    """ffc.py:258-292 (inline=False): (x_l, x_g) + conv2(conv1((x_l, x_g))); the add rides in conv2's epilogues."""
+
+    def __init__(self, dim, padding_type, norm_layer, activation_layer=nn.ReLU, dilation=1, spatial_transform_kwargs=None,
+                 inline=False, **conv_kwargs):
+        super().__init__()
+        if spatial_transform_kwargs is not None or inline or dilation != 1:
+            raise NotImplementedError('FFCResnetBlock: spatial transforms / inline / dilation are not used by big-lama')
+        self.conv1 = FFC_BN_ACT(dim, dim, kernel_size=3, padding=dilation, dilation=dilation, norm_layer=norm_layer,
+                                activation_layer=activation_layer, padding_type=padding_type, **conv_kwargs)
+        self.conv2 = FFC_BN_ACT(dim, dim, kernel_size=3, padding=dilation, dilation=dilation, norm_layer=norm_layer,
+                                activation_layer=activation_layer, padding_type=padding_type, **conv_kwargs)
+        self.inline = inline
+
+    def run(self, src: torch.Tensor, tmp: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict]):
+        self.conv1.run(src, tmp, scratch)
+        self.conv2.run(tmp, dst, scratch, resid=src)
+
+    def forward(self, x):
+        x_l, x_g = x if type(x) is tuple else (x, 0)
+        self._exec.check(x_l)
+        src, cl, cg = _pair_buffer(x_l, x_g)
+        tmp, dst = torch.empty_like(src), torch.empty_like(src)
+        self.run(src, tmp, dst, self.conv1.make_scratch(src.shape, src.device))
+        return (dst[:, :cl], dst[:, cl:]) if cg else (dst, 0)
+
+
+class ConcatTupleLayer(nn.Module):
+    """ffc.py:295-302.  Free when x_l | x_g already share one buffer (always the case on the fused path)."""
+
+    def forward(self, x):
+        assert isinstance(x, tuple)
+        x_l, x_g = x
+        assert torch.is_tensor(x_l) or torch.is_tensor(x_g)
+        if not torch.is_tensor(x_g):
+            return x_l
+        buf = _adjacent(x_l, x_g)
+        return buf if buf is not None else torch.cat(x, dim=1)
+
+
+# ----------------------------------------------------------------------------------------------------
+# stand-alone leaf layers of generator.model (used when a caller runs the Sequential layer by layer)
+# ----------------------------------------------------------------------------------------------------
+
+class ReflectionPad2d(_HipModule):
+    def __init__(self, padding: int):
+        super().__init__()
+        self.padding = int(padding)
+
+    def forward(self, x):
+        self._exec.check(x)
+        x = x.contiguous()
+        B, Cn, H, W = x.shape
+        y = torch.empty(B, Cn, H + 2 * self.padding, W + 2 * self.padding, device=x.device, dtype=torch.float32)
+        self._exec.lib.reflect_pad(L.view(x), self.padding, L.view(y), B, self._exec.stream(x))
+        return y
+
+
+class _Affine(_HipModule):
+    def _launch(self, x, scale, shift, act):
+        self._exec.check(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        self._exec.lib.affine_act(L.view(x), scale, shift, act, L.view(y), x.shape[0], self._exec.stream(x))
+        return y
+
+
+class BatchNorm2dEval(nn.BatchNorm2d, _Affine):
+    """nn.BatchNorm2d parameter container whose (eval) forward is the HIP affine kernel."""
+
+    def __init__(self, num_features):
+        nn.BatchNorm2d.__init__(self, num_features)
+        self._packed = None
+        self._exec = _DEFAULT_EXEC
+
+    def forward(self, x):
+        scale, shift = _bn_fold(self)
+        return self._launch(x, scale.contiguous(), shift.contiguous(), L.ACT_NONE)
+
+
+class Activation(_Affine):
+    def __init__(self, kind: str):
+        super().__init__()
+        self.kind = kind
+
+    def forward(self, x):
+        return self._launch(x, None, None, _ACT[self.kind])
+
+
+class ConvTranspose2dUp(nn.ConvTranspose2d, _HipModule):
+    """nn.ConvTranspose2d(k3, s2, p1, op1) parameter container (ffc.py:348-351) + HIP forward."""
+
+    def __init__(self, cin, cout):
+        nn.ConvTranspose2d.__init__(self, cin, cout, kernel_size=3, stride=2, padding=1, output_padding=1)
+        self._packed = None
+        self._exec = _DEFAULT_EXEC
+
+    def run(self, src, dst, bn: Optional[nn.BatchNorm2d] = None, act: int = L.ACT_NONE):
+        key = id(bn)
+        if self._packed is None or self._packed[0] != key:
+            if bn is not None:
+                scale, shift = _bn_fold(bn)
+                bias = self.bias.detach().float() * scale + shift
+            else:
+                scale, bias = None, self.bias.detach().float()
+            self._packed = (key, self._exec.lib.pack_conv_weight(self.weight.detach(), scale, stride=2, transposed=True,
+                                                                  precision=self.precision), bias.contiguous())
+        _, wp, bias = self._packed
+        self._exec.lib.conv2d(L.view(src), wp, L.view(dst), src.shape[0], 3, 2, 1, L.PAD_ZERO, True, bias, act,
+                              precision=self.precision, stream=self._exec.stream(src))
+
+    def forward(self, x, bn=None, act=L.ACT_NONE):
+        self._exec.check(x)
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        y = torch.empty(B, self.out_channels, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        self.run(x, y, bn, act)
+        return y
+
+
+class Conv2dOut(nn.Conv2d, _HipModule):
+    """The 7x7 output conv (ffc.py:361), optionally fused with the preceding reflection pad and the
+    output activation."""
+
+    def __init__(self, cin, cout, kernel_size=7, padding=0):
+        nn.Conv2d.__init__(self, cin, cout, kernel_size=kernel_size, padding=padding)
+        self._packed = None
+        self._exec = _DEFAULT_EXEC
+
+    def run(self, src, dst, extra_pad=0, act=L.ACT_NONE):
+        if self._packed is None:
+            self._packed = (self._exec.lib.pack_conv_weight(self.weight.detach(), None, precision=self.precision),
+                            self.bias.detach().float().contiguous())
+        wp, bias = self._packed
+        self._exec.lib.conv2d(L.view(src), wp, L.view(dst), src.shape[0], self.kernel_size[0], 1, self.padding[0] + extra_pad,
+                              L.PAD_REFLECT, False, bias, act, precision=self.precision, stream=self._exec.stream(src))
+
+    def forward(self, x, extra_pad=0, act=L.ACT_NONE):
+        self._exec.check(x)
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        k, p = self.kernel_size[0], self.padding[0] + extra_pad
+        y = torch.empty(B, self.out_channels, H + 2 * p - k + 1, W + 2 * p - k + 1, device=x.device, dtype=torch.float32)
+        self.run(x, y, extra_pad, act)
+        return y
+
+
+class LayerSequence(nn.Sequential):
+    """``generator.model``: indexable / sliceable like the reference's nn.Sequential (refinement.py:270-289,
+    predict_inner_features.py:56,84-86).  Its forward peephole-fuses the patterns the reference spells as
+    separate layers: ReflectionPad2d -> conv, ConvTranspose2d -> BatchNorm2d -> ReLU, conv -> output act."""
+
+    def forward(self, x):
+        layers = list(self)
+        i, n = 0, len(layers)
+        while i < n:
+            cur = layers[i]
+            nxt = layers[i + 1] if i + 1 < n else None
+            if isinstance(cur, ReflectionPad2d) and isinstance(nxt, FFC_BN_ACT) and torch.is_tensor(x):
+                x = nxt(x, extra_pad=cur.padding); i += 2
+            elif isinstance(cur, ReflectionPad2d) and isinstance(nxt, Conv2dOut):
+                act = layers[i + 2] if i + 2 < n and isinstance(layers[i + 2], Activation) else None
+                x = nxt(x, extra_pad=cur.padding, act=_ACT[act.kind] if act else L.ACT_NONE)
+                i += 3 if act else 2
+            elif isinstance(cur, ConvTranspose2dUp) and isinstance(nxt, BatchNorm2dEval) and i + 2 < n and \
+                    isinstance(layers[i + 2], Activation):
+                x = cur(x, bn=nxt, act=_ACT[layers[i + 2].kind]); i += 3
+            else:
+                x = cur(x); i += 1
+        return x
+
+
+# ----------------------------------------------------------------------------------------------------
+# the generator
+# ----------------------------------------------------------------------------------------------------
+
+class FFCResNetGenerator(_HipModule):
+    """ffc.py:305-367.  ``forward(x[B,input_nc,H,W]) -> [B,output_nc,H,W]``; ``.model`` has the reference's
+    36-entry layout (big-lama) and state_dict keys.
+
+    The fused forward keeps the bottleneck state (x_l | x_g) in one channel-contiguous buffer,
+    ping-pongs three such buffers through the residual blocks, reuses one scratch set for every
+    SpectralTransform, and (``use_graph=True``) replays the ~230 launches from a captured hipGraph.
+    """
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_downsampling=3, n_blocks=9, norm_layer=nn.BatchNorm2d,
+                 padding_type='reflect', activation_layer=nn.ReLU, up_norm_layer=nn.BatchNorm2d, up_activation=nn.ReLU(True),
+                 init_conv_kwargs={}, downsample_conv_kwargs={}, resnet_conv_kwargs={}, spatial_transform_layers=None,
+                 spatial_transform_kwargs={}, add_out_act=True, max_features=1024, out_ffc=False, out_ffc_kwargs={}):
+        assert (n_blocks >= 0)
+        super().__init__()
+        if spatial_transform_layers is not None or out_ffc:
+            raise NotImplementedError('spatial_transform_layers / out_ffc are not used by big-lama and not implemented')
+        if norm_layer is not nn.BatchNorm2d or up_norm_layer is not nn.BatchNorm2d or padding_type != 'reflect':
+            raise NotImplementedError('only BatchNorm2d + reflect padding (the big-lama configuration) are implemented')
+        up_act = 'relu' if isinstance(up_activation, nn.ReLU) else None
+        if up_act is None:
+            raise NotImplementedError('up_activation must be ReLU')
+
+        model: List[nn.Module] = [ReflectionPad2d(3),
+                                  FFC_BN_ACT(input_nc, ngf, kernel_size=7, padding=0, norm_layer=norm_layer,
+                                             activation_layer=activation_layer, **init_conv_kwargs)]
+        for i in range(n_downsampling):                                       # ffc.py:320-332
+            mult = 2 ** i
+            if i == n_downsampling - 1:
+                cur_conv_kwargs = dict(downsample_conv_kwargs)
+                cur_conv_kwargs['ratio_gout'] = resnet_conv_kwargs.get('ratio_gin', 0)
+            else:
+                cur_conv_kwargs = downsample_conv_kwargs
+            model += [FFC_BN_ACT(min(max_features, ngf * mult), min(max_features, ngf * mult * 2), kernel_size=3, stride=2,
+                                 padding=1, norm_layer=norm_layer, activation_layer=activation_layer, **cur_conv_kwargs)]
+        mult = 2 ** n_downsampling
+        feats_num_bottleneck = min(max_features, ngf * mult)
+        for i in range(n_blocks):                                             # ffc.py:338-343
+            model += [FFCResnetBlock(feats_num_bottleneck, padding_type=padding_type, activation_layer=activation_layer,
+                                     norm_layer=norm_layer, **resnet_conv_kwargs)]
+        model += [ConcatTupleLayer()]
+        for i in range(n_downsampling):                                       # ffc.py:348-354
+            mult = 2 ** (n_downsampling - i)
+            model += [ConvTranspose2dUp(min(max_features, ngf * mult), min(max_features, int(ngf * mult / 2))),
+                      BatchNorm2dEval(min(max_features, int(ngf * mult / 2))), Activation(up_act)]
+        model += [ReflectionPad2d(3), Conv2dOut(ngf, output_nc, kernel_size=7, padding=0)]
+        if add_out_act:                                                       # ffc.py:362-363 + base.get_activation
+            kind = 'tanh' if add_out_act is True else add_out_act
+            if kind not in ('tanh', 'sigmoid'):
+                raise ValueError(f'Unknown activation kind {kind}')
+            model.append(Activation(kind))
+        self.model = LayerSequence(*model)
+        self.use_graph = False
+        self._plans = {}
+        super().train(False)
+
+    # ------------------------------------------------------------------------------------------------
+    def _invalidate(self):
+        super()._invalidate()
+        self._plans = {}
+
+    def _build_plan(self, shape, device):
+        """Pre-allocate every activation buffer for an input shape and record the launch list."""
+        layers = list(self.model)
+        steps = []
+        bufs = {}
+        cur_shape = tuple(shape)
+        cur = 'in'
+        i, n = 0, len(layers)
+        pad_pending = 0
+
+        def new(name, shp):
+            bufs[name] = torch.empty(shp, device=device, dtype=torch.float32)
+            return name
+
+        scratch = None
+        k = 0
+        while i < n:
+            lay = layers[i]
+            if isinstance(lay, ReflectionPad2d):
+                pad_pending = lay.padding; i += 1; continue
+            if isinstance(lay, FFC_BN_ACT):
+                shp = lay.out_shape(cur_shape, pad_pending)
+                dst = new(f'a{k}', shp); k += 1
+                steps.append(('ffc', lay, cur, dst, pad_pending))
+                cur, cur_shape, pad_pending = dst, shp, 0
+            elif isinstance(lay, FFCResnetBlock):
+                if scratch is None:
+                    scratch = lay.conv1.make_scratch(cur_shape, device)
+                    new('rt', cur_shape); new('rA', cur_shape); new('rB', cur_shape)
+                dst = 'rA' if cur != 'rA' else 'rB'
+                steps.append(('res', lay, cur, 'rt', dst))
+                cur = dst
+            elif isinstance(lay, ConcatTupleLayer):
+                pass
+            elif isinstance(lay, ConvTranspose2dUp):
+                bn = layers[i + 1] if i + 1 < n and isinstance(layers[i + 1], BatchNorm2dEval) else None
+                act = layers[i + 2] if bn is not None and i + 2 < n and isinstance(layers[i + 2], Activation) else None
+                B, _, H, W = cur_shape
+                shp = (B, lay.out_channels, 2 * H, 2 * W)
+                dst = new(f'a{k}', shp); k += 1
+                if bn is not None and act is not None:
+                    steps.append(('up', lay, cur, dst, bn, _ACT[act.kind])); i += 2
+                else:
+                    steps.append(('up', lay, cur, dst, None, L.ACT_NONE))
+                cur, cur_shape = dst, shp
+            elif isinstance(lay, Conv2dOut):
+                act = layers[i + 1] if i + 1 < n and isinstance(layers[i + 1], Activation) else None
+                B, _, H, W = cur_shape
+                kk, p = lay.kernel_size[0], lay.padding[0] + pad_pending
+                shp = (B, lay.out_channels, H + 2 * p - kk + 1, W + 2 * p - kk + 1)
+                dst = new('out', shp)
+                steps.append(('out', lay, cur, dst, pad_pending, _ACT[act.kind] if act else L.ACT_NONE))
+                cur, cur_shape, pad_pending = dst, shp, 0
+                if act:
+                    i += 1
+            else:
+                raise LamaError(f'no fused plan for layer {type(lay).__name__}; run generator.model layer by layer')
+            i += 1
+        return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None)
+
+    def _run_plan(self, plan, x):
+        bufs = plan['bufs']
+
+        def B(name):
+            return x if name == 'in' else bufs[name]
+
+        for st in plan['steps']:
+            kind = st[0]
+            if kind == 'ffc':
+                _, lay, s, d, pad = st
+                lay.run(B(s), B(d), plan['scratch'] if lay.ffc.in_cg else None, None, pad)
+            elif kind == 'res':
+                _, lay, s, t, d = st
+                lay.run(B(s), B(t), B(d), plan['scratch'])
+            elif kind == 'up':
+                _, lay, s, d, bn, act = st
+                lay.run(B(s), B(d), bn, act)
+            else:
+                _, lay, s, d, pad, act = st
+                lay.run(B(s), B(d), pad, act)
+        return bufs[plan['out']]
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        self._exec.check(input)
+        x = input.contiguous()
+        key = (tuple(x.shape), str(x.device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = self._build_plan(x.shape, x.device)
+        if not (self.use_graph and x.is_cuda):
+            return self._run_plan(plan, x).clone()
+        if plan['graph'] is None:
+            plan['static_in'] = torch.empty_like(x)
+            plan['static_in'].copy_(x)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):           # warm-up (packs weights) outside capture
+                self._run_plan(plan, plan['static_in'])
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                plan['static_out'] = self._run_plan(plan, plan['static_in'])
+            plan['graph'] = g
+        plan['static_in'].copy_(x)
+        plan['graph'].replay()
+        return plan['static_out'].clone()

@@ -1,0 +1,137 @@
+"""CPU tests of the host-side mirror (lama_amd.ffc / trainers / config) driving the kernel sources
+through the host SIMT emulator, against the oracle and the reference-generated golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from lama_amd import config as lcfg
+from lama_amd import ffc as F
+from lama_amd import trainers
+from lama_amd.modules import make_generator
+from oracle import lama_oracle as O
+from tests.emu import emu_lib
+
+
+@pytest.fixture(scope='module')
+def small():
+    cfg = O.small_config(ngf=8, n_blocks=2)
+    sd = O.make_synthetic_state_dict(cfg, seed=7, calib_hw=32)
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    res = gen.load_state_dict(sd, strict=True)          # same keys as the reference
+    assert not res.missing_keys and not res.unexpected_keys
+    gen.set_exec(F._Exec(emu_lib()))
+    return cfg, sd, gen
+
+
+def test_state_dict_keys_match_reference_layout(small):
+    cfg, sd, gen = small
+    assert set(gen.state_dict().keys()) == set(sd.keys())
+    big = make_generator(None, kind='ffc_resnet', **O.BIG_LAMA)
+    keys = set(big.state_dict().keys())
+    assert len(keys) == 989 and keys == {k for k, _, r in O.state_dict_spec(O.BIG_LAMA) for k in
+                                         ([k] if r != 'bn' else [k + s for s in ('.weight', '.bias', '.running_mean', '.running_var', '.num_batches_tracked')])}
+    assert len(big.model) == 36 and sum(p.numel() for p in big.parameters()) == 50975875
+
+
+@pytest.mark.parametrize('case', ['a', 'b'])
+def test_generator_matches_golden(small, golden_dir, case):
+    cfg, sd, gen = small
+    g = np.load(os.path.join(golden_dir, 'small_gen.npz'))
+    x = torch.from_numpy(g[f'{case}_x'])
+    y = gen(x)
+    assert np.abs(y.numpy() - g[f'{case}_y']).max() < 1e-4
+
+
+def test_generator_fused_fft_path_and_layerwise(small):
+    cfg, sd, gen = small
+    batch = O.make_synthetic_batch(1, 128, 128, seed=3)          # bottleneck 16x16 -> fused LDS FFT kernels
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    taps = {}
+    with torch.no_grad():
+        ref = O.generator_forward(x, sd, cfg, taps=taps)
+    y = gen(x)
+    assert float((y - ref).abs().max()) < 1e-4
+    # layer-by-layer through generator.model (what refinement.py / predict_inner_features.py do)
+    z = x
+    for i, layer in enumerate(gen.model):
+        z = layer(z)
+        r = taps[i]
+        if isinstance(z, tuple):
+            assert float((z[0] - r[0]).abs().max()) < 2e-4
+            if torch.is_tensor(r[1]):
+                assert float((z[1] - r[1]).abs().max()) < 2e-4
+        else:
+            assert float((z - r).abs().max()) < 2e-4, i
+    # sliced Sequential keeps the fused forward
+    front, rear = gen.model[0:5], gen.model[5:]
+    assert float((rear(front(x)) - ref).abs().max()) < 1e-4
+
+
+def test_units_match_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ffc_units.npz'))
+    ex = F._Exec(emu_lib())
+    for tag in ('e', 'o', 'p', 'q'):
+        sd = {k[len(f'fu_{tag}_sd_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f'fu_{tag}_sd_')}
+        c = sd['bn.weight'].numel() // 2
+        fu = F.FourierUnit(c, c).set_exec(ex)
+        fu.load_state_dict(sd, strict=True)
+        y = fu(torch.from_numpy(g[f'fu_{tag}_x']))
+        assert np.abs(y.numpy() - g[f'fu_{tag}_y']).max() < 5e-5, tag
+    import torch.nn as nn
+    blk = F.FFCResnetBlock(16, padding_type='reflect', norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU,
+                           ratio_gin=0.75, ratio_gout=0.75, enable_lfu=False).set_exec(ex)
+    blk.load_state_dict({k[len('blk_sd_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('blk_sd_')}, strict=True)
+    xl, xg = torch.from_numpy(g['blk_xl']), torch.from_numpy(g['blk_xg'])
+    yl, yg = blk((xl, xg))
+    assert np.abs(yl.numpy() - g['blk_yl']).max() < 5e-5 and np.abs(yg.numpy() - g['blk_yg']).max() < 5e-5
+    l1, g1 = blk.conv1((xl, xg))
+    assert np.abs(l1.numpy() - g['blk_c1_l']).max() < 5e-5 and np.abs(g1.numpy() - g['blk_c1_g']).max() < 5e-5
+    st = blk.conv1.ffc.convg2g(xg)
+    assert np.abs(st.numpy() - g['blk_st']).max() < 5e-5
+    yl2, yg2 = blk((xl, xg))          # fused packing is restored after the stand-alone SpectralTransform call
+    assert torch.equal(yl2, yl) and torch.equal(yg2, yg)
+
+
+def test_training_module_and_checkpoint_roundtrip(small, tmp_path, golden_dir):
+    cfg, sd, gen = small
+    # a Lightning-style checkpoint dir: config.yaml with unresolved interpolations + models/best.ckpt
+    raw = dict(training_model=dict(kind='default', concat_mask=True, visualize_each_iters=1000),
+               generator=dict(kind='ffc_resnet', input_nc=4, output_nc=3, ngf=8, n_downsampling=3, n_blocks=2, add_out_act='sigmoid',
+                              init_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
+                              downsample_conv_kwargs=dict(ratio_gin='${generator.init_conv_kwargs.ratio_gout}',
+                                                          ratio_gout='${generator.downsample_conv_kwargs.ratio_gin}', enable_lfu=False),
+                              resnet_conv_kwargs=dict(ratio_gin=0.75, ratio_gout='${generator.resnet_conv_kwargs.ratio_gin}', enable_lfu=False)),
+               losses=dict(resnet_pl=dict(weights_path='${env:TORCH_HOME}')), visualizer=dict(kind='directory'))
+    os.makedirs(tmp_path / 'models')
+    with open(tmp_path / 'config.yaml', 'w') as f:
+        yaml.safe_dump(raw, f)
+    state = {'state_dict': {**{'generator.' + k: v for k, v in sd.items()}, 'discriminator.model0.0.weight': torch.zeros(3),
+                            'val_evaluator.scores.lpips.x': torch.zeros(2)}, 'optimizer_states': []}
+    torch.save(state, tmp_path / 'models' / 'best.ckpt')
+    tc = lcfg.load_train_config(str(tmp_path / 'config.yaml'))
+    assert tc['generator']['downsample_conv_kwargs']['ratio_gout'] == 0 and tc['generator']['resnet_conv_kwargs']['ratio_gout'] == 0.75
+    model = trainers.load_checkpoint(tc, str(tmp_path / 'models' / 'best.ckpt'), strict=False, map_location='cpu')
+    model.freeze()
+    model.generator.set_exec(F._Exec(emu_lib()))
+    g = np.load(os.path.join(golden_dir, 'predict_glue.npz'))
+    img_p = O.pad_img_to_modulo(g['image'], 8)
+    msk_p = O.pad_img_to_modulo(g['mask'][None], 8)
+    batch = dict(image=torch.from_numpy(img_p)[None], mask=(torch.from_numpy(msk_p)[None] > 0) * 1)
+    out = model(batch)
+    cur = out['inpainted'][0].permute(1, 2, 0).numpy()[:37, :50]
+    assert np.abs(cur - g['inpainted']).max() < 1e-4
+    with pytest.raises(RuntimeError):
+        trainers.load_checkpoint(tc, str(tmp_path / 'models' / 'best.ckpt'), strict=True, map_location='cpu')
+
+
+def test_product_path_has_no_cpu_fallback():
+    gen = make_generator(None, kind='ffc_resnet', **O.small_config(ngf=8, n_blocks=1))
+    with pytest.raises(F.LamaError):
+        gen(torch.zeros(1, 4, 32, 32))           # CPU tensor + real library -> refuse, never fall back
+    with pytest.raises(NotImplementedError):
+        F.SpectralTransform(8, 8, enable_lfu=True)
+    with pytest.raises(NotImplementedError):
+        gen.train()
