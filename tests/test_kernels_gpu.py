@@ -1,0 +1,135 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP library through the C ABI against torch fp32
+ops / the CPU oracle / the reference-generated golden vectors."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lama_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_kernels_emu import CONV_CASES, FFT_SIZES, _conv_ref, _inv_ref, _spec_ref  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def lib():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return L.get_lib()          # raises if liblama_hip.so was not built: no fallback
+
+
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d(lib, case):
+    g = torch.Generator().manual_seed(1)
+    B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
+    tr = case.get('transposed', False)
+    x = torch.randn(B, cin, case['H'], case['W'], generator=g)
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
+    bias = torch.randn(cout, generator=g) if case['bias'] else None
+    ref0 = _conv_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
+    resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
+    ref = _conv_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
+    wp = lib.pack_conv_weight(w.to(DEV), None if scale is None else scale.to(DEV), stride=case['stride'], transposed=tr)
+    ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0, device=DEV)
+    xd = x.to(DEV)
+    rd = None if resid is None else resid.to(DEV)
+    bd = None if bias is None else bias.to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.conv2d(L.view(xd), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'],
+               L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bd, case['act'], None if rd is None else L.view(rd), stream=st)
+    torch.cuda.synchronize()
+    y = ybuf[:, 2:2 + cout].cpu()
+    assert torch.allclose(y, ref, atol=2e-4, rtol=1e-4), float((y - ref).abs().max())
+    assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0
+
+
+@pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
+                                   (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56)])
+def test_conv2d_big_tiles(lib, shape):
+    """Full-size channel counts (BM=128 tiles, many K chunks) against torch fp32 on the GPU's host."""
+    B, cin, cout, k, H, W = shape
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = _conv_ref(x, w, 1, k // 2, True, False, bias, 1, None)
+    y = torch.empty(B, cout, H, W, device=DEV)
+    xd, bd = x.to(DEV), bias.to(DEV)             # keep the device copies alive until the kernel ran
+    wp = lib.pack_conv_weight(w.to(DEV), None)
+    lib.conv2d(L.view(xd), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bd, L.ACT_RELU,
+               stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.allclose(y.cpu(), ref, atol=3e-4, rtol=1e-4), float((y.cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize('hw', FFT_SIZES + [(128, 128), (256, 256), (168, 168)], ids=lambda s: f'{s[0]}x{s[1]}')
+def test_rfft2_irfft2(lib, hw):
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 131 + w)
+    B, Cn = 2, 3
+    wide = torch.randn(B, Cn + 2, h, w, generator=g)
+    x = wide[:, 1:1 + Cn]
+    wd = wide.to(DEV)
+    spec = torch.zeros(B, 2 * Cn, h, w // 2 + 1, device=DEV)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rfft2(L.view(wd, 1, Cn), L.view(spec), B, ws, stream=st)
+    ref = _spec_ref(x)
+    tol = 3e-5 if max(h, w) <= 128 else 2e-4
+    assert torch.allclose(spec.cpu(), ref, atol=tol, rtol=1e-4), float((spec.cpu() - ref).abs().max())
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g))
+    resid = torch.randn(B, Cn, h, w, generator=g)
+    y = torch.zeros(B, Cn, h, w, device=DEV)
+    s2d, rd = spec2.to(DEV), resid.to(DEV)
+    lib.irfft2(L.view(s2d), L.view(rd), L.view(y), B, ws, stream=st)
+    ref2 = resid + _inv_ref(spec2, h, w)
+    assert torch.allclose(y.cpu(), ref2, atol=tol, rtol=1e-4), float((y.cpu() - ref2).abs().max())
+
+
+def test_fourier_unit_c2_shape(lib):
+    """FourierUnit at the BASELINE config-2 shape [8,192,64,64] against the oracle."""
+    from oracle import lama_oracle as O
+    g = torch.Generator().manual_seed(5)
+    B, Cn, h, w = 8, 192, 64, 64
+    x = torch.randn(B, Cn, h, w, generator=g)
+    sd = {'fu.conv_layer.weight': torch.randn(2 * Cn, 2 * Cn, 1, 1, generator=g) / (2 * Cn) ** 0.5,
+          'fu.bn.weight': torch.rand(2 * Cn, generator=g) + 0.5, 'fu.bn.bias': torch.randn(2 * Cn, generator=g) * 0.2,
+          'fu.bn.running_mean': torch.randn(2 * Cn, generator=g) * 0.1, 'fu.bn.running_var': torch.rand(2 * Cn, generator=g) + 0.5}
+    with torch.no_grad():
+        ref = x + O.fourier_unit(x, sd, 'fu')
+    scale = sd['fu.bn.weight'] / torch.sqrt(sd['fu.bn.running_var'] + 1e-5)
+    shift = sd['fu.bn.bias'] - sd['fu.bn.running_mean'] * scale
+    wp = lib.pack_conv_weight(sd['fu.conv_layer.weight'].to(DEV), scale.to(DEV))
+    ws = torch.zeros(lib.fourier_unit_workspace_bytes(B, Cn, h, w) // 4 + 1, device=DEV)
+    xd = x.to(DEV)
+    y = torch.zeros_like(xd)
+    shd = shift.to(DEV)
+    lib.fourier_unit(L.view(xd), wp, shd, L.view(y), B, True, ws, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert float((y.cpu() - ref).abs().max()) < 1e-4
+
+
+def test_elementwise(lib):
+    g = torch.Generator().manual_seed(9)
+    B, H, W = 2, 40, 56
+    img, mask = torch.rand(B, 3, H, W, generator=g), (torch.rand(B, 1, H, W, generator=g) > 0.5).float()
+    pred = torch.rand(B, 3, H, W, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    out = torch.zeros(B, 4, H, W, device=DEV)
+    imgd, maskd, predd = img.to(DEV), mask.to(DEV), pred.to(DEV)
+    lib.mask_compose(L.view(imgd), L.view(maskd), L.view(out), B, st)
+    assert torch.equal(out.cpu(), torch.cat([img * (1 - mask), mask], 1))
+    bl = torch.zeros(B, 3, H, W, device=DEV)
+    lib.blend(L.view(imgd), L.view(maskd), L.view(predd), L.view(bl), B, st)
+    assert torch.allclose(bl.cpu(), mask * pred + (1 - mask) * img, atol=1e-6)
+    src = torch.rand(B, 3, H, W, generator=g) * 1.2 - 0.1
+    u8 = torch.zeros(B, 37, 50, 3, dtype=torch.uint8, device=DEV)
+    srcd = src.to(DEV)
+    lib.quantize_u8_hwc(L.view(srcd), u8, B, 37, 50, st)
+    ref = np.clip(src.permute(0, 2, 3, 1).numpy()[:, :37, :50] * 255, 0, 255).astype('uint8')
+    assert np.array_equal(u8.cpu().numpy(), ref)

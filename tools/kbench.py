@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at BASELINE config-2 shapes (B=8, 512x512 -> bottleneck 64x64).  Writes JSON to
+gpurun_out/kbench.json.  Times are medians of HIP-event pairs on the launch stream."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lama_amd import _lib as L  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    lib = L.get_lib()
+    dev = 'cuda'
+    st = torch.cuda.current_stream().cuda_stream
+    B, h, w = 8, 64, 64
+    res = {}
+    g = torch.Generator().manual_seed(0)
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g).to(dev)
+
+    def conv_case(name, cin, cout, k, H, W, stride=1, tr=False, x2c=0, flops=None, bytes_=None):
+        x = rnd(B, cin, H, W)
+        wt = rnd(cin, cout, k, k) if tr else rnd(cout, cin, k, k)
+        stride = 2 if tr else stride
+        wp = lib.pack_conv_weight(wt, None, stride=stride, transposed=tr)
+        Ho, Wo = (2 * H, 2 * W) if tr else ((H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1)
+        y = torch.empty(B, cout, Ho, Wo, device=dev)
+        bias = rnd(cout)
+        x2 = w2p = None
+        if x2c:
+            x2 = rnd(B, x2c, Ho, Wo); w2p = lib.pack_conv_weight(rnd(cout, x2c, 1, 1), None)
+        fn = lambda: lib.conv2d(L.view(x), wp, L.view(y), B, k, stride, 1 if tr else k // 2, L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
+                                L.ACT_RELU, None, None if x2 is None else L.view(x2), w2p, stream=st)
+        med, mn = timeit(fn)
+        fl = 2.0 * B * Ho * Wo * cout * (cin * k * k / (4 if tr else 1) * (2.25 / 2.25 if not tr else 1) + x2c) if flops is None else flops
+        if tr:
+            fl = 2.0 * B * H * W * cout * cin * 9
+        res[name] = dict(us=med, us_min=mn, tflops=fl / med / 1e6, gflop=fl / 1e9)
+        print(name, res[name], flush=True)
+
+    conv_case('conv3x3_512to128 (l2l+g2l)', 512, 128, 3, h, w)
+    conv_case('conv3x3_128to384+1x1_192 (l2g+conv2)', 128, 384, 3, h, w, x2c=192)
+    conv_case('conv1x1_384to192 (st.conv1)', 384, 192, 1, h, w)
+    conv_case('conv1x1_384to384_spec (fu.conv)', 384, 384, 1, h, 33)
+    conv_case('stem7x7_4to64', 4, 64, 7, 512, 512)
+    conv_case('down3x3s2_64to128', 64, 128, 3, 512, 512, stride=2)
+    conv_case('down3x3s2_128to256', 128, 256, 3, 256, 256, stride=2)
+    conv_case('down3x3s2_256to512', 256, 512, 3, 128, 128, stride=2)
+    conv_case('up_512to256', 512, 256, 3, 64, 64, tr=True)
+    conv_case('up_256to128', 256, 128, 3, 128, 128, tr=True)
+    conv_case('up_128to64', 128, 64, 3, 256, 256, tr=True)
+    conv_case('head7x7_64to3', 64, 3, 7, 512, 512)
+
+    # FFT kernels
+    x1 = rnd(B, 192, h, w)
+    spec = torch.empty(B, 384, h, w // 2 + 1, device=dev)
+    y = torch.empty_like(x1)
+    med, mn = timeit(lambda: lib.rfft2(L.view(x1), L.view(spec), B, None, st))
+    res['rfft2_8x192x64x64'] = dict(us=med, us_min=mn, gbps=(x1.numel() + spec.numel()) * 4 / med / 1e3)
+    med, mn = timeit(lambda: lib.irfft2(L.view(spec), L.view(x1), L.view(y), B, None, st))
+    res['irfft2_add_8x192x64x64'] = dict(us=med, us_min=mn, gbps=(2 * x1.numel() + spec.numel()) * 4 / med / 1e3)
+    wp = lib.pack_conv_weight(rnd(384, 384, 1, 1), None)
+    bias = rnd(384)
+    ws = torch.empty(lib.fourier_unit_workspace_bytes(B, 192, h, w) // 4 + 1, device=dev)
+    med, mn = timeit(lambda: lib.fourier_unit(L.view(x1), wp, bias, L.view(y), B, True, ws, stream=st))
+    alg = 2 * x1.numel() * 4 + 384 * 384 * 4 + 384 * 4
+    res['fourier_unit_8x192x64x64'] = dict(us=med, us_min=mn, alg_bytes=alg, alg_gbps=alg / med / 1e3, frac_of_8TBs=alg / med / 1e3 / 8000)
+    for k in ('rfft2_8x192x64x64', 'irfft2_add_8x192x64x64', 'fourier_unit_8x192x64x64'):
+        print(k, res[k], flush=True)
+
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'kbench.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
