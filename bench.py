@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Benchmark of the LaMa FFC hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): inpainted images/s at 512x512, big-lama, fp32.  One *step* = one pass of the
+hot path over one batch of synthetic input per rank: mask compose -> FFCResNetGenerator (big-lama,
+random-init weights of that architecture) -> blend -> u8 quantisation, on a batch of 8 images of
+512x512 that is already resident in HBM when the timed region starts (BASELINE configs[1];
+N ranks = configs[3] per rank).  N > 1: one process per GPU (torch.distributed over RCCL), images are
+sharded data-parallel (weak scaling, 8 per rank) and the only data-path collective is the all-gather
+of the u8 output images, inside the timed region.
+
+The JSON line also carries
+  roofline      -- the dominant kernel of the step (by total time): algorithmic FLOPs per launch /
+                   its average launch duration, measured here with HIP events on the launch stream
+                   in instrumented eager steps after the timed region (graph replay cannot be
+                   bracketed per kernel); profiles/ holds the rocprofv3 --kernel-trace --stats summary
+                   of this same command for cross-checking.
+  roofline_ffc  -- the unit BASELINE.json names: FourierUnit forward (rfft2 -> spectral 1x1+BN+ReLU ->
+                   irfft2 + residual), algorithmic bytes / time against the 8 TB/s HBM peak.
+  cpu_baseline  -- the oracle (CPU restatement of the reference, same torch-CPU primitives) timed on
+                   the host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from lama_amd import _lib as L  # noqa: E402
+from lama_amd import trainers  # noqa: E402
+
+BIG_LAMA = dict(
+    kind='ffc_resnet', input_nc=4, output_nc=3, ngf=64, n_downsampling=3, n_blocks=18, add_out_act='sigmoid',
+    init_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
+    downsample_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
+    resnet_conv_kwargs=dict(ratio_gin=0.75, ratio_gout=0.75, enable_lfu=False))
+BATCH, RES = 8, 512
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0
+
+
+def synthetic_batch(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.floor(torch.rand(BATCH, 3, RES, RES, generator=g) * 256) / 255.0
+    mask = torch.zeros(BATCH, 1, RES, RES)
+    mask[:, :, RES // 4: 3 * RES // 4, RES // 4: 3 * RES // 4] = 1.0
+    return img.to(device), mask.to(device)
+
+
+def build_model(device, precision):
+    torch.manual_seed(0)
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(BIG_LAMA)))
+    # random-init weights; give the BatchNorms non-trivial statistics so nothing folds to identity
+    g = torch.Generator().manual_seed(1)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data = torch.rand(m.weight.shape, generator=g) + 0.5
+            m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.2
+            m.running_mean.data = torch.randn(m.bias.shape, generator=g) * 0.1
+            m.running_var.data = torch.rand(m.bias.shape, generator=g) + 0.5
+    model.freeze().to(device)
+    model.generator.set_precision(precision)
+    return model
+
+
+class KernelTimer:
+    """HIP-event pairs around selected C-ABI launches (eager steps only)."""
+
+    def __init__(self, lib):
+        self.lib, self.records, self.on = lib, {}, False
+        self._conv, self._fu = lib.conv2d, lib.fourier_unit
+        lib.conv2d, lib.fourier_unit = self.conv2d, self.fourier_unit
+
+    def _timed(self, key, fn, *a, **kw):
+        if not self.on:
+            return fn(*a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*a, **kw)
+        e1.record()
+        self.records.setdefault(key, []).append((e0, e1))
+
+    def conv2d(self, x, w_packed, y, batch, k, *a, **kw):
+        x2 = kw.get("x2", a[7] if len(a) > 7 else None)
+        key = f'conv{k}x{k}_cin{x.C}_cout{y.C}' + (f'+1x1_cin{x2.C}' if x2 is not None else '')
+        return self._timed(key, self._conv, x, w_packed, y, batch, k, *a, **kw)
+
+    def fourier_unit(self, x, *a, **kw):
+        return self._timed(f'fourier_unit_c{x.C}_{x.H}x{x.W}', self._fu, x, *a, **kw)
+
+    def summary(self):
+        out = {}
+        for k, evs in self.records.items():
+            ts = [a.elapsed_time(b) * 1e3 for a, b in evs]
+            out[k] = dict(n=len(ts), avg_us=sum(ts) / len(ts), total_us=sum(ts))
+        return out
+
+
+def cpu_baseline(model, budget_s=20.0):
+    """Oracle (oracle/lama_oracle.py = the reference's arithmetic on torch-CPU) on a bounded sample:
+    batch-1 loop over 512x512 images as bin/predict.py does, default torch threading."""
+    from oracle import lama_oracle as O
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = {k: v for k, v in BIG_LAMA.items() if k != 'kind'}
+    img, mask = synthetic_batch('cpu', 1234)
+    n, t_used = 0, 0.0
+    with torch.no_grad():
+        O.training_module_forward(dict(image=img[:1, :, :128, :128].clone(), mask=mask[:1, :, :128, :128].clone()), sd, cfg)  # warm-up
+        while n < BATCH and (n < 2 or t_used < budget_s):
+            t0 = time.perf_counter()
+            O.training_module_forward(dict(image=img[n:n + 1].clone(), mask=mask[n:n + 1].clone()), sd, cfg)
+            t_used += time.perf_counter() - t0
+            n += 1
+    return dict(value=round(n / t_used, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} of the {BATCH} 512x512 images, batch-1 loop (bin/predict.py mode), oracle/lama_oracle.py '
+                       f'(reference arithmetic on torch-CPU {torch.__version__}), {t_used:.1f} s, host has {os.cpu_count()} logical cores')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--precision', default=os.environ.get('LAMA_PRECISION', 'f32'), choices=['f32', 'bf16x3'])
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    precision = L.PREC_F32 if args.precision == 'f32' else L.PREC_BF16X3
+
+    lib = L.get_lib()                      # raises if the HIP library is missing: no fallback
+    timer = KernelTimer(lib)
+    model = build_model(device, precision)
+    model.generator.use_graph = not args.no_graph
+    img, mask = synthetic_batch(device, 1234 + rank)
+    u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
+    gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if world > 1 else None
+
+    def step():
+        out = model(dict(image=img, mask=mask))
+        lib.quantize_u8_hwc(L.view(out['inpainted']), u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, u8)       # the only data-path collective: output images
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # instrumented eager steps: per-kernel durations with HIP events on the launch stream
+    roof = roof_ffc = None
+    kern = {}
+    if rank == 0:
+        model.generator.use_graph = False
+        step()
+        torch.cuda.synchronize()
+        timer.on = True
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        timer.on = False
+        kern = timer.summary()
+        dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])
+        h = RES // 8
+        flops = {'conv3x3_cin128_cout384+1x1_cin192': 2.0 * BATCH * h * h * 384 * (128 * 9 + 192),
+                 'conv3x3_cin512_cout128': 2.0 * BATCH * h * h * 128 * 512 * 9}.get(dom)
+        peak = MFMA_F32_PEAK_TF if precision == L.PREC_F32 else MFMA_BF16_PEAK_TF / 3.0
+        if flops:
+            ach = flops / kern[dom]['avg_us'] / 1e6
+            roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
+                        traffic=None, avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
+                        note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
+                             '3-term bf16 split: peak = bf16 dense peak / 3 products')
+        fu = next((k for k in kern if k.startswith('fourier_unit')), None)
+        if fu:
+            alg = 2 * BATCH * 192 * h * h * 4 + 384 * 384 * 4 + 384 * 4       # read x, write y, weights once
+            gbs = alg / kern[fu]['avg_us'] / 1e3
+            roof_ffc = dict(unit_of_work='FourierUnit forward [8,192,64,64] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
+                            peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                            avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(model)
+
+    if rank == 0:
+        total_images = world * BATCH * args.steps
+        line = {
+            'metric': 'inpainted images/sec at 512x512 big-lama',
+            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if precision == L.PREC_F32 else 'f32 via 3-term bf16 MFMA split', 'data': 'synthetic',
+            'config': {'workload': f'big-lama FFCResNetGenerator 512x512 batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
+                                   f'mask-compose + generator + blend + u8, random-init weights',
+                       'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
+                       'hip_graph': not args.no_graph, 'precision': args.precision},
+            'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu,
+            'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['total_us'])},
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
