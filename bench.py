@@ -77,6 +77,7 @@ class KernelTimer:
 
     def __init__(self, lib):
         self.lib, self.records, self.on = lib, {}, False
+        self.flops, self.bytes = {}, {}
         self._conv, self._fu = lib.conv2d, lib.fourier_unit
         lib.conv2d, lib.fourier_unit = self.conv2d, self.fourier_unit
 
@@ -91,7 +92,12 @@ class KernelTimer:
 
     def conv2d(self, x, w_packed, y, batch, k, *a, **kw):
         x2 = kw.get("x2", a[7] if len(a) > 7 else None)
-        key = f'conv{k}x{k}_cin{x.C}_cout{y.C}' + (f'+1x1_cin{x2.C}' if x2 is not None else '')
+        tr = kw.get("transposed", a[3] if len(a) > 3 else False)
+        key = f'conv{k}x{k}{"T" if tr else ""}_cin{x.C}_cout{y.C}_{y.H}x{y.W}' + (f'+1x1_cin{x2.C}' if x2 is not None else '')
+        # algorithmic FLOPs of the launch (2*M*N*K; a transposed conv touches 9/4 taps per output pixel)
+        kterm = x.C * k * k / (4.0 if tr else 1.0) + (x2.C if x2 is not None else 0)
+        self.flops[key] = 2.0 * batch * y.H * y.W * y.C * kterm
+        self.bytes[key] = 4.0 * batch * (x.C * x.H * x.W + y.C * y.H * y.W + (x2.C * x2.H * x2.W if x2 is not None else 0))
         return self._timed(key, self._conv, x, w_packed, y, batch, k, *a, **kw)
 
     def fourier_unit(self, x, *a, **kw):
@@ -103,6 +109,21 @@ class KernelTimer:
             ts = [a.elapsed_time(b) * 1e3 for a, b in evs]
             out[k] = dict(n=len(ts), avg_us=sum(ts) / len(ts), total_us=sum(ts))
         return out
+
+
+def pmc_traffic(kernel_key, precision):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/*pmc*.json, collected
+    with this same workload; a live bench run cannot host the profiler) or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc*.json')), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        e = d.get(precision, {}).get(kernel_key)
+        if e:
+            return e
+    return None
 
 
 def cpu_baseline(model, budget_s=20.0):
@@ -130,7 +151,8 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', default=os.environ.get('LAMA_PRECISION', 'f32'), choices=['f32', 'bf16x3'])
+    ap.add_argument('--precision', default=os.environ.get('LAMA_PRECISION', 'bf16x3'), choices=['f32', 'bf16x3'])
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-fp32 timing leg')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
@@ -198,15 +220,16 @@ def main():
         kern = timer.summary()
         dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])
         h = RES // 8
-        flops = {'conv3x3_cin128_cout384+1x1_cin192': 2.0 * BATCH * h * h * 384 * (128 * 9 + 192),
-                 'conv3x3_cin512_cout128': 2.0 * BATCH * h * h * 128 * 512 * 9}.get(dom)
+        flops = timer.flops.get(dom)
         peak = MFMA_F32_PEAK_TF if precision == L.PREC_F32 else MFMA_BF16_PEAK_TF / 3.0
         if flops:
             ach = flops / kern[dom]['avg_us'] / 1e6
-            roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                        traffic=None, avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
+            roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
+                        traffic=pmc_traffic(dom, args.precision), avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
+                        algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
-                             '3-term bf16 split: peak = bf16 dense peak / 3 products')
+                             'fp32 accuracy via 3-term bf16 split on v_mfma_f32_32x32x16_bf16: peak = 2500 TF dense bf16 / 3 MFMA products per '
+                             'algorithmic product; achieved counts algorithmic FLOPs only')
         fu = next((k for k in kern if k.startswith('fourier_unit')), None)
         if fu:
             alg = 2 * BATCH * 192 * h * h * 4 + 384 * 384 * 4 + 384 * 4       # read x, write y, weights once
@@ -214,6 +237,24 @@ def main():
             roof_ffc = dict(unit_of_work='FourierUnit forward [8,192,64,64] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
                             peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
                             avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg)
+
+    # extra leg (rank 0, N = 1): the same step on the exact-fp32 MFMA path, for reference beside the default bf16x3 split
+    f32_leg = None
+    if rank == 0 and world == 1 and precision != L.PREC_F32 and not args.no_f32_leg:
+        model.generator.set_precision(L.PREC_F32)
+        model.generator.use_graph = not args.no_graph
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nf = max(3, args.steps // 4)
+        for _ in range(nf):
+            step()
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        f32_leg = dict(value=round(BATCH * nf / d1, 3), unit='images/s', ms_per_step=round(d1 / nf * 1e3, 3), steps=nf,
+                       note='same workload on v_mfma_f32_32x32x2_f32 (exact fp32, 157.3 TF peak)')
+        model.generator.set_precision(precision)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -225,12 +266,12 @@ def main():
             'metric': 'inpainted images/sec at 512x512 big-lama',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if precision == L.PREC_F32 else 'f32 via 3-term bf16 MFMA split', 'data': 'synthetic',
+            'dtype': 'f32' if precision == L.PREC_F32 else 'f32 (3-term bf16-split MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',
             'config': {'workload': f'big-lama FFCResNetGenerator 512x512 batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
                                    f'mask-compose + generator + blend + u8, random-init weights',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'hip_graph': not args.no_graph, 'precision': args.precision},
-            'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu,
+            'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['total_us'])},
         }
         print(json.dumps(line), flush=True)

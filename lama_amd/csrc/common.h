@@ -33,3 +33,15 @@ __device__ __forceinline__ int lama_xcd_remap(int orig, int nwg) {
     int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + idx;
 }
+
+// LDS (address space 3) pointer for __builtin_amdgcn_global_load_lds; the destination is the
+// wave-uniform base, the hardware adds lane * size.  (tests/hipemu overrides this for the host build.)
+#ifndef LAMA_LDS_PTR
+#define LAMA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#endif
+
+// bf16x3 convolution back end (conv_bf16x3.hip), reached through lama_conv2d_* with LAMA_PREC_BF16X3
+int64_t lama_cb_packed_weight_bytes(int cout, int cin, int kh, int kw, int stride, int transposed);
+int lama_cb_pack_weight(hipStream_t stream, const float* w, const float* scale, int cout, int cin, int kh, int kw, int stride,
+                        int transposed, void* dst);
+int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, int Wo);

@@ -1,0 +1,599 @@
+// Fused implicit-GEMM convolution on the gfx950 bf16 matrix cores with a 3-term split that keeps
+// fp32-class accuracy (LAMA_PREC_BF16X3):
+//
+//   x = xh + xl,  w = wh + wl   (xh = bf16(x) RNE, xl = bf16(x - xh); same for w)
+//   w*x ~= wh*xh + wh*xl + wl*xh          (dropped wl*xl term: 2^-16 relative)
+//
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: three MFMAs per product at 16x the rate of the
+// exact v_mfma_f32_32x32x2_f32 path (conv_mfma.hip).  Same fused math as there:
+//
+//   y[b,o,p] = act( sum_{c,t} W1[o,c,t] x[b,c,tap_t(p)] [+ sum_c W2[o,c] x2[b,c,p]] + bias[o] ) [+ resid[b,o,p]]
+//
+// GEMM view per image: M = output channels, N = output pixels (the contiguous NCHW axis -> MFMA
+// columns, coalesced loads / stores with no layout transform in HBM), K = (channel chunk, tap).
+//
+// Workgroup = 512 threads = 8 waves (2 per SIMD), output tile BM channels x BN pixels (BN = 128, a
+// TH x TW rectangle; BM = 32 uses 8 waves along N, BN = 256).  K is walked in *stages* of TG taps x
+// 16*KS channels (TG*KS MFMA k-steps of 16):
+//   * weights: pre-split into (hi, lo) bf16 and pre-packed in MFMA A-fragment order by
+//     lama_conv2d_pack_weight, so a stage is ONE contiguous image that the waves stream into LDS with
+//     16-byte global_load_lds DMA (no VGPRs, no VALU) and read back with linear, conflict-free
+//     ds_read_b128; two LDS buffers, the DMA of stage s+1 flies during the MFMAs of stage s;
+//   * activations: the input *patch* of a channel chunk (tile + halo, reflection / zero padding
+//     applied, stride-2 columns parity-split) is loaded fp32 from HBM/L2 one chunk ahead into
+//     registers, split into hi/lo bf16 ONCE per element (v_cvt_pk_bf16_f32) and written to LDS as
+//     [channel octet][pixel][8 x bf16] planes: a B fragment (8 consecutive channels of one pixel) is
+//     one ds_read_b128, consecutive lanes = consecutive pixels = conflict free for every tap; the
+//     9x / 49x im2col reuse never leaves the CU; two patch buffers, ONE barrier per stage.
+// A second K segment (1x1 over x2) chains into the same accumulators:
+//   out_xg = convl2g(x_l) + convg2g.conv2(x1 + fu(x1))  (ffc.py:161,223) + BN shift + ReLU + residual.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CB_THREADS 512
+#define CB_MAX_TAPS 49
+
+struct CbSeg {
+    const float* x;
+    long long bstride;
+    int C, H, W;
+    const char* w;       // packed stage images of this sub-convolution; M-tile mt starts at w + mt*mt_bytes
+    long long mt_bytes;
+    int nchunk, NG;      // channel chunks (16*KS channels each), tap groups (TG taps each) per chunk
+    int stride, pad_mode;
+    int dy0, dx0;        // patch origin relative to (gy*stride, gx*stride)
+    int PH, PW;          // patch rows / cols (real pixels)
+    int PWs, PWh;        // LDS row pitch in pixels; parity-split half width (stride 2) or 0
+    int npix;            // pixels per LDS octet plane
+    int tapoff[CB_MAX_TAPS];  // LDS pixel offset of tap t inside the patch
+};
+
+struct CbParams {
+    CbSeg s1, s2;
+    const float* bias;
+    const float* resid;
+    long long resid_bstride;
+    float* y;
+    long long y_bstride;
+    int M, MT;
+    int Ho, Wo;
+    int GH, GW, oy0, ox0, ostep;
+    int TWlog, tiles_x, tiles_y, B;
+    int act;
+    int wbytes, pbytes;  // bytes of ONE weight-stage buffer / ONE patch buffer (hi + lo planes)
+};
+
+template <int BM>
+struct CbGeom {
+    static constexpr int WAVES_M = (BM >= 64) ? 2 : 1;
+    static constexpr int WAVES_N = 8 / WAVES_M;
+    static constexpr int BN = WAVES_N * 32;
+    static constexpr int TM = BM / WAVES_M / 32;  // 32-row fragments per wave
+    static constexpr int MF = BM / 32;            // fragments per M tile
+};
+
+__device__ __forceinline__ int cb_src_coord(int i, int n, int pad_mode) {
+    if (pad_mode == LAMA_PAD_REFLECT) {
+        if (i < 0) i = -i;
+        if (i >= n) i = 2 * (n - 1) - i;
+        if (i < 0) i = 0;  // only reachable for pixels of a ragged tile that are never stored
+        if (i >= n) i = n - 1;
+        return i;
+    }
+    return (i < 0 || i >= n) ? -1 : i;
+}
+
+// (hi, lo) bf16 split of two floats, packed as two dwords (element 0 in the low half)
+__device__ __forceinline__ void cb_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    f32x2 v = {a, b};
+    bf16x2 h = __builtin_convertvector(v, bf16x2);
+    f32x2 r = v - __builtin_convertvector(h, f32x2);
+    bf16x2 l = __builtin_convertvector(r, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+// One K segment: accumulate into acc.
+template <int TG, int KS, int BM, int MAXU>
+__device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy0, int gx0, int TWlog, char* wbuf0, int wbytes,
+                                           char* pbuf0, int pbytes, f32x16 (&acc)[CbGeom<BM>::TM]) {
+    using G = CbGeom<BM>;
+    constexpr int NOCT = 2 * KS;                    // channel octets per chunk
+    constexpr int BKC = 16 * KS;                    // channels per chunk
+    constexpr int NPIECE = TG * KS * G::MF * 2;     // 1-KiB fragment images per weight stage
+    constexpr int WROUNDS = (NPIECE + 7) / 8;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int TW = 1 << TWlog;
+    const int HW = s.H * s.W;
+    const int NPR = s.PH * s.PW;
+    const int nunits = NPR * NOCT;
+    const int plo = NOCT * s.npix * 16;             // byte offset of the lo planes inside a patch buffer
+
+    // per-thread staging units: (patch pixel, channel octet) -> source offset, LDS byte offset
+    int src_off[MAXU], lds_off[MAXU], uq[MAXU];
+#pragma unroll
+    for (int i = 0; i < MAXU; ++i) {
+        int u = i * CB_THREADS + tid;
+        int so = -1, lo = -1, q = 0;
+        if (u < nunits) {
+            q = u / NPR;
+            int pp = u - q * NPR;
+            int py = pp / s.PW, px = pp - py * s.PW;
+            int iy = cb_src_coord(gy0 * s.stride + s.dy0 + py, s.H, s.pad_mode);
+            int ix = cb_src_coord(gx0 * s.stride + s.dx0 + px, s.W, s.pad_mode);
+            if (iy >= 0 && ix >= 0) so = iy * s.W + ix;
+            int lidx = py * s.PWs + (s.PWh ? (px & 1) * s.PWh + (px >> 1) : px);
+            lo = (q * s.npix + lidx) * 16;
+        }
+        src_off[i] = so;
+        lds_off[i] = lo;
+        uq[i] = q;
+    }
+    // B-fragment base: this lane's pixel inside the patch, octet plane khalf
+    int boff;
+    {
+        int n = wn * 32 + l31;
+        int ty = n >> TWlog, tx = n & (TW - 1);
+        int pixoff = ty * s.stride * s.PWs + (s.PWh ? tx : tx * s.stride);
+        boff = (khalf * s.npix + pixoff) * 16;
+    }
+    const int aoff = (wm * G::TM * 2) * 1024 + lane * 16;  // A fragments of this wave inside a k-step image
+
+    const float* xb = s.x + (long long)b * s.bstride;
+    const char* wsrc = s.w + (long long)mt * s.mt_bytes;
+    const int S = s.nchunk * s.NG;
+    constexpr int WST = NPIECE * 1024;
+
+    float preg[MAXU][8];
+    auto load_patch = [&](int ch) {
+        const float* xc = xb + (long long)ch * BKC * HW;
+        const int crem = s.C - ch * BKC;
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const int so = src_off[i];
+            const int c0 = uq[i] * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) preg[i][e] = (so >= 0 && c0 + e < crem) ? xc[(long long)(c0 + e) * HW + so] : 0.0f;
+        }
+    };
+    auto write_patch = [&](char* pb) {
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            if (lds_off[i] >= 0) {
+                uint4 h, l;
+                cb_split2(preg[i][0], preg[i][1], h.x, l.x);
+                cb_split2(preg[i][2], preg[i][3], h.y, l.y);
+                cb_split2(preg[i][4], preg[i][5], h.z, l.z);
+                cb_split2(preg[i][6], preg[i][7], h.w, l.w);
+                *reinterpret_cast<uint4*>(pb + lds_off[i]) = h;
+                *reinterpret_cast<uint4*>(pb + plo + lds_off[i]) = l;
+            }
+        }
+    };
+    auto stage_weights = [&](int st, char* wb) {
+        const char* g = wsrc + (long long)st * WST;
+#pragma unroll
+        for (int r = 0; r < WROUNDS; ++r) {
+            int piece = r * 8 + wave;
+            if (piece < NPIECE)
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(g + piece * 1024 + lane * 16), LAMA_LDS_PTR(wb + piece * 1024),
+                                                 16, 0, 0);
+        }
+    };
+
+    // prologue: stage 0 weights, chunk 0 patch, chunk 1 in flight
+    stage_weights(0, wbuf0);
+    load_patch(0);
+    write_patch(pbuf0);
+    if (s.nchunk > 1) load_patch(1);
+    __syncthreads();
+
+    int st = 0;
+    for (int ch = 0; ch < s.nchunk; ++ch) {
+        const char* pb = pbuf0 + (ch & 1) * pbytes;
+        for (int g = 0; g < s.NG; ++g, ++st) {
+            const char* wb = wbuf0 + (st & 1) * wbytes;
+            if (st + 1 < S) stage_weights(st + 1, wbuf0 + ((st + 1) & 1) * wbytes);
+            if (g == s.NG - 1 && ch + 1 < s.nchunk) {
+                // next chunk's patch (loaded a chunk ago) -> the other buffer; then start the chunk after
+                write_patch(pbuf0 + ((ch + 1) & 1) * pbytes);
+                if (ch + 2 < s.nchunk) load_patch(ch + 2);
+            }
+#pragma unroll
+            for (int tgi = 0; tgi < TG; ++tgi) {
+                const int toff = s.tapoff[g * TG + tgi] * 16;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int kk = tgi * KS + ks;
+                    const char* bp = pb + (ks * 2 * s.npix) * 16 + boff + toff;
+                    bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
+                    bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + plo);
+#pragma unroll
+                    for (int i = 0; i < G::TM; ++i) {
+                        const char* ap = wb + (kk * G::MF * 2 + i * 2) * 1024 + aoff;
+                        bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                        bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 1024);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int TG1, int KS1, int TG2, int KS2, int BM, int MAXU>
+__global__ __launch_bounds__(CB_THREADS) void conv_bf16x3_kernel(CbParams p) {
+    using G = CbGeom<BM>;
+    char* wbuf0 = lama_smem;
+    char* pbuf0 = lama_smem + 2 * p.wbytes;
+
+    const int L = lama_xcd_remap(blockIdx.x, gridDim.x);
+    const int mt = L % p.MT;
+    int tile = L / p.MT;
+    const int tix = tile % p.tiles_x;
+    tile /= p.tiles_x;
+    const int tiy = tile % p.tiles_y;
+    const int b = tile / p.tiles_y;
+    const int TW = 1 << p.TWlog, TH = G::BN >> p.TWlog;
+    const int gy0 = tiy * TH, gx0 = tix * TW;
+
+    f32x16 acc[G::TM];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    cb_segment<TG1, KS1, BM, MAXU>(p.s1, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
+    if constexpr (TG2 > 0) cb_segment<TG2, KS2, BM, MAXU>(p.s2, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
+
+    // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
+    const long long plane = (long long)p.Ho * p.Wo;
+    const int n = wn * 32 + (lane & 31);
+    const int gy = gy0 + (n >> p.TWlog), gx = gx0 + (n & (TW - 1));
+    const bool pv = gy < p.GH && gx < p.GW;
+    const long long pix = (long long)(gy * p.ostep + p.oy0) * p.Wo + (gx * p.ostep + p.ox0);
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = mt * BM + (wm * G::TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (pv && m < p.M) {
+                float v = acc[i][r];
+                if (p.bias) v += p.bias[m];
+                if (p.act == LAMA_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (p.act == LAMA_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                else if (p.act == LAMA_ACT_TANH) v = tanhf(v);
+                long long o = m * plane + pix;
+                if (p.resid) v += p.resid[(long long)b * p.resid_bstride + o];
+                p.y[(long long)b * p.y_bstride + o] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: reference layout fp32 -> per (M tile, stage) images of (hi, lo) bf16 A fragments
+//   image of one stage: [k-step kk = tgi*KS + ks][fragment mf][hi|lo][lane][8 x bf16]
+//   lane l of fragment mf holds output channel m = mt*BM + mf*32 + (l&31),
+//   input channels c = ch*16*KS + ks*16 + 8*(l>>5) + e  (e = 0..7), tap t = g*TG + tgi
+// ------------------------------------------------------------------------------------------------
+struct CbPackParams {
+    const float* w;
+    const float* scale;
+    char* dst;
+    int M, C, BM, MT, TG, KS, NG, nchunk;
+    int kh, kw, transposed;
+    int tap_ky[CB_MAX_TAPS], tap_kx[CB_MAX_TAPS];
+};
+
+__global__ void conv_bf16x3_pack_kernel(CbPackParams p) {
+    const int MF = p.BM / 32;
+    const long long per_stage = (long long)p.TG * p.KS * MF * 64;  // (kk, mf, lane) items; each writes hi and lo 16 B
+    const long long total = (long long)p.MT * p.nchunk * p.NG * per_stage;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        int lane = (int)(it & 63);
+        long long r = it >> 6;
+        int mf = (int)(r % MF);
+        r /= MF;
+        int kk = (int)(r % (p.TG * p.KS));
+        r /= (p.TG * p.KS);
+        int g = (int)(r % p.NG);
+        r /= p.NG;
+        int ch = (int)(r % p.nchunk);
+        int mt = (int)(r / p.nchunk);
+        int tgi = kk / p.KS, ks = kk - tgi * p.KS;
+        int t = g * p.TG + tgi;
+        int m = mt * p.BM + mf * 32 + (lane & 31);
+        int c0 = ch * 16 * p.KS + ks * 16 + 8 * (lane >> 5);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int c = c0 + e;
+            float x = 0.0f;
+            if (m < p.M && c < p.C) {
+                int ky = p.tap_ky[t], kx = p.tap_kx[t];
+                long long src = p.transposed ? (((long long)c * p.M + m) * p.kh + ky) * p.kw + kx
+                                             : (((long long)m * p.C + c) * p.kh + ky) * p.kw + kx;
+                x = p.w[src];
+                if (p.scale) x *= p.scale[m];
+            }
+            v[e] = x;
+        }
+        uint4 h, l;
+        cb_split2(v[0], v[1], h.x, l.x);
+        cb_split2(v[2], v[3], h.y, l.y);
+        cb_split2(v[4], v[5], h.z, l.z);
+        cb_split2(v[6], v[7], h.w, l.w);
+        long long stage = ((long long)mt * p.nchunk + ch) * p.NG + g;
+        char* base = p.dst + (stage * p.TG * p.KS * MF * 2 + ((long long)kk * MF + mf) * 2) * 1024 + lane * 16;
+        *reinterpret_cast<uint4*>(base) = h;
+        *reinterpret_cast<uint4*>(base + 1024) = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side: plan, pack, launch
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct CbPlan {
+    int BM, MT;
+    int nseg;  // sub-convolutions (1, or 4 output-parity classes for ConvTranspose2d)
+    int T[4], TG[4], KS[4];
+    int ky[4][CB_MAX_TAPS], kx[4][CB_MAX_TAPS];  // weight tap
+    int dy[4][CB_MAX_TAPS], dx[4][CB_MAX_TAPS];  // input offset of the tap
+    int oy0[4], ox0[4];
+    int nchunk[4];
+    long long mt_bytes[4], woff[4];
+    long long total_bytes;
+};
+
+int cb_pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+
+bool cb_stage_shape(int T, int* TG, int* KS) {
+    switch (T) {
+        case 1: *TG = 1; *KS = 2; return true;
+        case 2: *TG = 2; *KS = 1; return true;
+        case 4: *TG = 4; *KS = 1; return true;
+        case 9: *TG = 3; *KS = 1; return true;
+        case 49: *TG = 7; *KS = 1; return true;
+    }
+    return false;
+}
+
+bool cb_make_plan(int cout, int cin, int kh, int kw, int stride, int pad, int transposed, CbPlan* pl) {
+    pl->BM = cb_pick_bm(cout);
+    pl->MT = lama_ceil_div(cout, pl->BM);
+    if (transposed) {
+        if (kh != 3 || kw != 3 || stride != 2 || pad != 1) return false;
+        pl->nseg = 4;
+        for (int cls = 0; cls < 4; ++cls) {
+            int py = cls >> 1, px = cls & 1;
+            int kys[2], dys[2], nky, kxs[2], dxs[2], nkx;
+            if (py == 0) { nky = 1; kys[0] = 1; dys[0] = 0; } else { nky = 2; kys[0] = 0; dys[0] = 1; kys[1] = 2; dys[1] = 0; }
+            if (px == 0) { nkx = 1; kxs[0] = 1; dxs[0] = 0; } else { nkx = 2; kxs[0] = 0; dxs[0] = 1; kxs[1] = 2; dxs[1] = 0; }
+            int t = 0;
+            for (int a = 0; a < nky; ++a)
+                for (int c = 0; c < nkx; ++c) {
+                    pl->ky[cls][t] = kys[a]; pl->kx[cls][t] = kxs[c];
+                    pl->dy[cls][t] = dys[a]; pl->dx[cls][t] = dxs[c];
+                    ++t;
+                }
+            pl->T[cls] = t;
+            pl->oy0[cls] = py; pl->ox0[cls] = px;
+        }
+    } else {
+        if (!((kh == 1 && kw == 1) || (kh == 3 && kw == 3) || (kh == 7 && kw == 7))) return false;
+        if (stride != 1 && stride != 2) return false;
+        pl->nseg = 1;
+        int t = 0;
+        for (int a = 0; a < kh; ++a)
+            for (int c = 0; c < kw; ++c) {
+                pl->ky[0][t] = a; pl->kx[0][t] = c;
+                pl->dy[0][t] = a - pad; pl->dx[0][t] = c - pad;
+                ++t;
+            }
+        pl->T[0] = t;
+        pl->oy0[0] = pl->ox0[0] = 0;
+    }
+    long long off = 0;
+    for (int cls = 0; cls < pl->nseg; ++cls) {
+        if (!cb_stage_shape(pl->T[cls], &pl->TG[cls], &pl->KS[cls])) return false;
+        pl->nchunk[cls] = lama_ceil_div(cin, 16 * pl->KS[cls]);
+        long long stage = (long long)pl->TG[cls] * pl->KS[cls] * (pl->BM / 32) * 2048;
+        pl->mt_bytes[cls] = (long long)pl->nchunk[cls] * (pl->T[cls] / pl->TG[cls]) * stage;
+        pl->woff[cls] = off;
+        off += pl->mt_bytes[cls] * pl->MT;
+    }
+    pl->total_bytes = off;
+    return true;
+}
+
+// fill one segment for a tile of TH x TW output pixels; returns the staging units it needs
+int cb_fill_seg(CbSeg* s, const lama_tensor& x, const char* w, const CbPlan& pl, int cls, int stride, int pad_mode, int TH, int TW,
+                bool flat) {
+    const int T = pl.T[cls];
+    s->x = (const float*)x.ptr;
+    s->bstride = x.batch_stride;
+    s->C = x.C;
+    s->H = flat ? 1 : x.H;
+    s->W = flat ? x.H * x.W : x.W;
+    s->w = w;
+    s->mt_bytes = pl.mt_bytes[cls];
+    s->nchunk = pl.nchunk[cls];
+    s->NG = T / pl.TG[cls];
+    s->stride = stride;
+    s->pad_mode = pad_mode;
+    int dymin = 1 << 30, dymax = -(1 << 30), dxmin = 1 << 30, dxmax = -(1 << 30);
+    for (int t = 0; t < T; ++t) {
+        dymin = pl.dy[cls][t] < dymin ? pl.dy[cls][t] : dymin;
+        dymax = pl.dy[cls][t] > dymax ? pl.dy[cls][t] : dymax;
+        dxmin = pl.dx[cls][t] < dxmin ? pl.dx[cls][t] : dxmin;
+        dxmax = pl.dx[cls][t] > dxmax ? pl.dx[cls][t] : dxmax;
+    }
+    s->dy0 = dymin;
+    s->dx0 = dxmin;
+    s->PH = (TH - 1) * stride + (dymax - dymin) + 1;
+    s->PW = (TW - 1) * stride + (dxmax - dxmin) + 1;
+    if (stride == 2) {
+        s->PWh = (s->PW + 1) / 2;
+        s->PWs = 2 * s->PWh;
+    } else {
+        s->PWh = 0;
+        s->PWs = s->PW;
+    }
+    s->npix = s->PH * s->PWs;
+    for (int t = 0; t < T; ++t) {
+        int ry = pl.dy[cls][t] - dymin, rx = pl.dx[cls][t] - dxmin;
+        s->tapoff[t] = ry * s->PWs + (s->PWh ? (rx & 1) * s->PWh + (rx >> 1) : rx);
+    }
+    return s->PH * s->PW * 2 * pl.KS[cls];
+}
+
+template <int TG1, int KS1, int TG2, int KS2, int BM>
+int cb_launch_u(hipStream_t st, const CbParams& p, int maxu, int grid, size_t shmem) {
+    if (maxu <= 1) hipLaunchKernelGGL((conv_bf16x3_kernel<TG1, KS1, TG2, KS2, BM, 1>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
+    else if (maxu <= 3) hipLaunchKernelGGL((conv_bf16x3_kernel<TG1, KS1, TG2, KS2, BM, 3>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
+    else if (maxu <= 5) hipLaunchKernelGGL((conv_bf16x3_kernel<TG1, KS1, TG2, KS2, BM, 5>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
+    else return LAMA_ERR_UNSUPPORTED;
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+template <int TG1, int KS1, int TG2, int KS2>
+int cb_launch_bm(hipStream_t st, const CbParams& p, int BM, int maxu, int grid, size_t shmem) {
+    switch (BM) {
+        case 128: return cb_launch_u<TG1, KS1, TG2, KS2, 128>(st, p, maxu, grid, shmem);
+        case 64: return cb_launch_u<TG1, KS1, TG2, KS2, 64>(st, p, maxu, grid, shmem);
+        case 32: return cb_launch_u<TG1, KS1, TG2, KS2, 32>(st, p, maxu, grid, shmem);
+    }
+    return LAMA_ERR_UNSUPPORTED;
+}
+
+int cb_launch(hipStream_t st, const CbParams& p, int TG1, int KS1, int TG2, int KS2, int BM, int maxu) {
+    const size_t shmem = 2 * (size_t)p.wbytes + 2 * (size_t)p.pbytes;
+    if (shmem > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
+    const int grid = p.B * p.tiles_x * p.tiles_y * p.MT;
+    if (grid <= 0) return LAMA_OK;
+#define CB_CASE(t1, k1, t2, k2) \
+    if (TG1 == t1 && KS1 == k1 && TG2 == t2 && KS2 == k2) return cb_launch_bm<t1, k1, t2, k2>(st, p, BM, maxu, grid, shmem);
+    CB_CASE(3, 1, 0, 0)
+    CB_CASE(3, 1, 1, 2)
+    CB_CASE(1, 2, 0, 0)
+    CB_CASE(7, 1, 0, 0)
+    CB_CASE(2, 1, 0, 0)
+    CB_CASE(4, 1, 0, 0)
+#undef CB_CASE
+    return LAMA_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+int64_t lama_cb_packed_weight_bytes(int cout, int cin, int kh, int kw, int stride, int transposed) {
+    CbPlan pl;
+    if (!cb_make_plan(cout, cin, kh, kw, stride, transposed ? 1 : kh / 2, transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
+    return pl.total_bytes;
+}
+
+int lama_cb_pack_weight(hipStream_t stream, const float* w, const float* scale, int cout, int cin, int kh, int kw, int stride,
+                        int transposed, void* dst) {
+    CbPlan pl;
+    if (!cb_make_plan(cout, cin, kh, kw, stride, transposed ? 1 : kh / 2, transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
+    for (int cls = 0; cls < pl.nseg; ++cls) {
+        CbPackParams pp;
+        memset(&pp, 0, sizeof(pp));
+        pp.w = w;
+        pp.scale = scale;
+        pp.dst = (char*)dst + pl.woff[cls];
+        pp.M = cout;
+        pp.C = cin;
+        pp.BM = pl.BM;
+        pp.MT = pl.MT;
+        pp.TG = pl.TG[cls];
+        pp.KS = pl.KS[cls];
+        pp.NG = pl.T[cls] / pl.TG[cls];
+        pp.nchunk = pl.nchunk[cls];
+        pp.kh = kh;
+        pp.kw = kw;
+        pp.transposed = transposed;
+        for (int t = 0; t < pl.T[cls]; ++t) { pp.tap_ky[t] = pl.ky[cls][t]; pp.tap_kx[t] = pl.kx[cls][t]; }
+        long long total = pl.mt_bytes[cls] * pl.MT / 32;  // items of 2 x 16 B
+        int grid = (int)((total + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(conv_bf16x3_pack_kernel, dim3(grid), dim3(256), 0, stream, pp);
+        LAMA_CHECK_LAUNCH();
+    }
+    return LAMA_OK;
+}
+
+// arguments were validated by lama_conv2d_fwd (conv_mfma.hip)
+int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, int Wo) {
+    const int cout = a->y.C, cin = a->x.C;
+    CbPlan pl;
+    if (!cb_make_plan(cout, cin, a->kh, a->kw, a->stride, a->pad, a->transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
+    const bool has2 = a->x2.ptr != nullptr;
+    CbPlan pl2;
+    if (has2 && (!cb_make_plan(cout, a->x2.C, 1, 1, 1, 0, 0, &pl2) || pl2.BM != pl.BM)) return LAMA_ERR_UNSUPPORTED;
+    const int BN = pl.BM >= 64 ? 128 : 256;
+
+    for (int cls = 0; cls < pl.nseg; ++cls) {
+        CbParams p;
+        memset(&p, 0, sizeof(p));
+        const bool flat = (pl.T[cls] == 1 && !a->transposed && a->stride == 1 && a->pad == 0 && !has2);
+        p.bias = a->bias;
+        p.resid = (const float*)a->resid.ptr;
+        p.resid_bstride = a->resid.batch_stride;
+        p.y = (float*)a->y.ptr;
+        p.y_bstride = a->y.batch_stride;
+        p.M = cout;
+        p.MT = pl.MT;
+        p.B = a->batch;
+        p.act = a->act;
+        if (flat) {
+            p.Ho = 1; p.Wo = Ho * Wo; p.GH = 1; p.GW = Ho * Wo; p.ostep = 1;
+        } else if (a->transposed) {
+            p.Ho = Ho; p.Wo = Wo; p.GH = a->x.H; p.GW = a->x.W; p.ostep = 2;
+            p.oy0 = pl.oy0[cls]; p.ox0 = pl.ox0[cls];
+        } else {
+            p.Ho = Ho; p.Wo = Wo; p.GH = Ho; p.GW = Wo; p.ostep = 1;
+        }
+        const int stride = a->transposed ? 1 : a->stride;
+        const int pad_mode = a->transposed ? LAMA_PAD_ZERO : a->pad_mode;
+        // tile: TW = 32 output pixels of one row per wave (conflict-free B fragments), narrower only for narrow images
+        int twlog = flat ? lama_ilog2(BN) : 5;
+        while (twlog > 3 && (1 << (twlog - 1)) >= p.GW) --twlog;
+        const int TW = 1 << twlog, TH = BN >> twlog;
+        p.TWlog = twlog;
+        p.tiles_x = lama_ceil_div(p.GW, TW);
+        p.tiles_y = lama_ceil_div(p.GH, TH);
+        int units = cb_fill_seg(&p.s1, a->x, (const char*)a->w_packed + pl.woff[cls], pl, cls, stride, pad_mode, TH, TW, flat);
+        long long wbytes = (long long)pl.TG[cls] * pl.KS[cls] * (pl.BM / 32) * 2048;
+        long long pbytes = (long long)2 * 2 * pl.KS[cls] * p.s1.npix * 16;
+        int TG2 = 0, KS2 = 0;
+        if (has2) {
+            TG2 = pl2.TG[0]; KS2 = pl2.KS[0];
+            int u2 = cb_fill_seg(&p.s2, a->x2, (const char*)a->w2_packed, pl2, 0, 1, LAMA_PAD_ZERO, TH, TW, false);
+            units = u2 > units ? u2 : units;
+            long long w2 = (long long)TG2 * KS2 * (pl.BM / 32) * 2048, p2 = (long long)2 * 2 * KS2 * p.s2.npix * 16;
+            wbytes = w2 > wbytes ? w2 : wbytes;
+            pbytes = p2 > pbytes ? p2 : pbytes;
+        }
+        p.wbytes = (int)wbytes;
+        p.pbytes = (int)pbytes;
+        int rc = cb_launch(stream, p, pl.TG[cls], pl.KS[cls], TG2, KS2, pl.BM, lama_ceil_div(units, CB_THREADS));
+        if (rc != LAMA_OK) return rc;
+    }
+    return LAMA_OK;
+}

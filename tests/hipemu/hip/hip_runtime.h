@@ -214,6 +214,11 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(V8 a, V8 b, hipemu_f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32_16x16x4f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_f32_32x32x16_bf16(a, b, c)
 
+// LDS-DMA: every lane copies `size` bytes from its own global address to (wave-uniform LDS base + lane*size)
+#define LAMA_LDS_PTR(p) ((void*)(p))
+static inline void hipemu_global_load_lds(const void* g, void* l, int size) { memcpy((char*)l + hipemu::lane() * size, g, size); }
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu_global_load_lds((const char*)(g) + (off), l, size)
+
 // math helpers that exist in HIP device code
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
 static inline void sincospif(float x, float* s, float* c) { *s = (float)sin(M_PI * (double)x); *c = (float)cos(M_PI * (double)x); }

@@ -11,38 +11,51 @@ from lama_amd import trainers
 from lama_amd.modules import make_generator
 from oracle import lama_oracle as O
 
+from lama_amd import _lib as L
+
 pytestmark = pytest.mark.gpu
-TOL = 2e-4
+# north_star bar: 1e-3 max-abs fp32.  Held here: 2e-4 for the exact-fp32 MFMA path, 3e-4 for the 3-term bf16 split.
+TOLS = {L.PREC_F32: 2e-4, L.PREC_BF16X3: 3e-4}
+
+
+@pytest.fixture(scope='module', params=[L.PREC_F32, L.PREC_BF16X3], ids=['f32', 'bf16x3'])
+def prec(request):
+    return request.param
 
 
 @pytest.fixture(scope='module')
-def small_gen():
+def small_gen(prec):
     cfg = O.small_config(ngf=8, n_blocks=2)
     sd = O.make_synthetic_state_dict(cfg, seed=7, calib_hw=32)
     gen = make_generator(None, kind='ffc_resnet', **cfg)
     gen.load_state_dict(sd, strict=True)
-    return cfg, sd, gen.cuda()
+    return cfg, sd, gen.cuda().set_precision(prec), TOLS[prec]
+
+
+_BIG_SD = {}
 
 
 @pytest.fixture(scope='module')
-def big():
+def big(prec):
     cfg = O.BIG_LAMA
-    sd = O.make_synthetic_state_dict(cfg, seed=0, calib_hw=64)
+    if 'sd' not in _BIG_SD:
+        _BIG_SD['sd'] = O.make_synthetic_state_dict(cfg, seed=0, calib_hw=64)
+    sd = _BIG_SD['sd']
     gen = make_generator(None, kind='ffc_resnet', **cfg)
     gen.load_state_dict(sd, strict=True)
-    return cfg, sd, gen.cuda()
+    return cfg, sd, gen.cuda().set_precision(prec), TOLS[prec]
 
 
 @pytest.mark.parametrize('case', ['a', 'b', 'c'])
 def test_small_generator_golden(small_gen, golden_dir, case):
-    cfg, sd, gen = small_gen
+    cfg, sd, gen, TOL = small_gen
     g = np.load(os.path.join(golden_dir, 'small_gen.npz'))
     y = gen(torch.from_numpy(g[f'{case}_x']).cuda())
     assert np.abs(y.cpu().numpy() - g[f'{case}_y']).max() < TOL
 
 
 def test_small_generator_layerwise_and_sliced(small_gen):
-    cfg, sd, gen = small_gen
+    cfg, sd, gen, TOL = small_gen
     batch = O.make_synthetic_batch(2, 128, 128, seed=3)
     x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
     taps = {}
@@ -55,13 +68,13 @@ def test_small_generator_layerwise_and_sliced(small_gen):
         z = layer(z)
         zz = z[0] if isinstance(z, tuple) else z
         rr = taps[i][0] if isinstance(taps[i], tuple) else taps[i]
-        assert float((zz.cpu() - rr).abs().max()) < 5e-4, i
+        assert float((zz.cpu() - rr).abs().max()) < 1e-3, i
     assert float((gen.model[5:](gen.model[0:5](xd)).cpu() - ref).abs().max()) < TOL
 
 
 def test_biglama_256_golden_and_oracle(big, golden_dir):
     """big-lama shape, 1x256x256: against the reference-generated samples and the full oracle output."""
-    cfg, sd, gen = big
+    cfg, sd, gen, TOL = big
     g = np.load(os.path.join(golden_dir, 'biglama_256.npz'))
     batch = O.make_synthetic_batch(1, 256, 256, seed=1234)
     x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
@@ -75,7 +88,7 @@ def test_biglama_256_golden_and_oracle(big, golden_dir):
 def test_biglama_c1_config_and_graph(big):
     """BASELINE configs[0] shape (4x256x256) through the training-module forward (mask compose + blend),
     eager launches and hipGraph replay must agree with the oracle and with each other."""
-    cfg, sd, gen = big
+    cfg, sd, gen, TOL = big
     batch = O.make_synthetic_batch(4, 256, 256, seed=77)
     sdg = {'generator.' + k: v for k, v in sd.items()}
     with torch.no_grad():
@@ -83,6 +96,7 @@ def test_biglama_c1_config_and_graph(big):
     model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
     model.load_state_dict(sdg, strict=True)
     model.freeze().cuda()
+    model.generator.set_precision(gen.precision)
     out = model(dict(image=batch['image'].cuda(), mask=batch['mask'].cuda()))
     assert float((out['inpainted'].cpu() - ref['inpainted']).abs().max()) < TOL
     model.generator.use_graph = True
@@ -96,7 +110,7 @@ def test_biglama_512_batch8_properties(big):
     """BASELINE configs[1] size (8x512x512): too slow for a full CPU oracle pass in a unit test, so check
     size-independent properties: batch independence (each image equals its batch-1 run), determinism,
     and blend exactness outside the hole."""
-    cfg, sd, gen = big
+    cfg, sd, gen, TOL = big
     batch = O.make_synthetic_batch(8, 512, 512, seed=99)
     x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
     y = gen(x)
@@ -112,7 +126,7 @@ def test_biglama_512_batch8_properties(big):
 
 def test_odd_sized_input_generic_fft(big):
     """H, W multiples of 8 only -> bottleneck 21x27 (odd, non power-of-two): generic DFT kernels."""
-    cfg, sd, gen = big
+    cfg, sd, gen, TOL = big
     batch = O.make_synthetic_batch(1, 168, 216, seed=5)
     x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
     with torch.no_grad():

@@ -44,8 +44,14 @@ CONV_CASES = [
 ]
 
 
+PRECISIONS = [L.PREC_F32, L.PREC_BF16X3]
+# max-abs tolerance: the exact-fp32 MFMA path is an fmaf chain; the 3-term bf16 split drops wl*xl (2^-16 relative per product)
+CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-4, rtol=2e-4)}
+
+
+@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
-def test_conv2d_emulated(case):
+def test_conv2d_emulated(case, prec):
     lib = emu_lib()
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
@@ -57,17 +63,18 @@ def test_conv2d_emulated(case):
     ref0 = _conv_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
     resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
     ref = _conv_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
-    wp = lib.pack_conv_weight(w, scale, stride=case['stride'], transposed=tr)
+    wp = lib.pack_conv_weight(w, scale, stride=case['stride'], transposed=tr, precision=prec)
     # write into a channel slice of a wider buffer to exercise the view arithmetic
     ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0)
     lib.conv2d(L.view(x), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'],
-               L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias, case['act'], None if resid is None else L.view(resid))
+               L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias, case['act'], None if resid is None else L.view(resid), precision=prec)
     y = ybuf[:, 2:2 + cout]
-    assert torch.allclose(y, ref, atol=2e-4, rtol=1e-4), float((y - ref).abs().max())
+    assert torch.allclose(y, ref, **CONV_TOL[prec]), float((y - ref).abs().max())
     assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0   # nothing written outside the view
 
 
-def test_conv2d_fused_second_operand_emulated():
+@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+def test_conv2d_fused_second_operand_emulated(prec):
     """out_g = relu(convl2g(x_l) + conv2(t) + b) + resid in one launch (ffc.py:161,223,253-254,288)."""
     lib = emu_lib()
     g = torch.Generator().manual_seed(2)
@@ -79,9 +86,10 @@ def test_conv2d_fused_second_operand_emulated():
     scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
     ref = _conv_ref(state[:, :cl], w1, 1, 1, True, False, bias, 1, state[:, cl:], x2=t, w2=w2 * scale[:, None, None, None], scale=scale)
     out = torch.zeros_like(state)
-    lib.conv2d(L.view(state, 0, cl), lib.pack_conv_weight(w1, scale), L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT, False, bias,
-               L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale))
-    assert torch.allclose(out[:, cl:], ref, atol=2e-4, rtol=1e-4), float((out[:, cl:] - ref).abs().max())
+    lib.conv2d(L.view(state, 0, cl), lib.pack_conv_weight(w1, scale, precision=prec), L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT,
+               False, bias, L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale, precision=prec),
+               precision=prec)
+    assert torch.allclose(out[:, cl:], ref, **CONV_TOL[prec]), float((out[:, cl:] - ref).abs().max())
 
 
 def _spec_ref(x):

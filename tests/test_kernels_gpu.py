@@ -10,7 +10,7 @@ from lama_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-from tests.test_kernels_emu import CONV_CASES, FFT_SIZES, _conv_ref, _inv_ref, _spec_ref  # noqa: E402
+from tests.test_kernels_emu import CONV_CASES, CONV_TOL, FFT_SIZES, PRECISIONS, _conv_ref, _inv_ref, _spec_ref  # noqa: E402
 
 
 @pytest.fixture(scope='module')
@@ -22,8 +22,9 @@ def lib():
 DEV = 'cuda'
 
 
+@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
-def test_conv2d(lib, case):
+def test_conv2d(lib, case, prec):
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)
@@ -34,23 +35,24 @@ def test_conv2d(lib, case):
     ref0 = _conv_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
     resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
     ref = _conv_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
-    wp = lib.pack_conv_weight(w.to(DEV), None if scale is None else scale.to(DEV), stride=case['stride'], transposed=tr)
+    wp = lib.pack_conv_weight(w.to(DEV), None if scale is None else scale.to(DEV), stride=case['stride'], transposed=tr, precision=prec)
     ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0, device=DEV)
     xd = x.to(DEV)
     rd = None if resid is None else resid.to(DEV)
     bd = None if bias is None else bias.to(DEV)
     st = torch.cuda.current_stream().cuda_stream
     lib.conv2d(L.view(xd), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'],
-               L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bd, case['act'], None if rd is None else L.view(rd), stream=st)
+               L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bd, case['act'], None if rd is None else L.view(rd), precision=prec, stream=st)
     torch.cuda.synchronize()
     y = ybuf[:, 2:2 + cout].cpu()
-    assert torch.allclose(y, ref, atol=2e-4, rtol=1e-4), float((y - ref).abs().max())
+    assert torch.allclose(y, ref, **CONV_TOL[prec]), float((y - ref).abs().max())
     assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0
 
 
+@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
 @pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
-                                   (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56)])
-def test_conv2d_big_tiles(lib, shape):
+                                   (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64)])
+def test_conv2d_big_tiles(lib, shape, prec):
     """Full-size channel counts (BM=128 tiles, many K chunks) against torch fp32 on the GPU's host."""
     B, cin, cout, k, H, W = shape
     g = torch.Generator().manual_seed(4)
@@ -60,11 +62,32 @@ def test_conv2d_big_tiles(lib, shape):
     ref = _conv_ref(x, w, 1, k // 2, True, False, bias, 1, None)
     y = torch.empty(B, cout, H, W, device=DEV)
     xd, bd = x.to(DEV), bias.to(DEV)             # keep the device copies alive until the kernel ran
-    wp = lib.pack_conv_weight(w.to(DEV), None)
-    lib.conv2d(L.view(xd), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bd, L.ACT_RELU,
+    wp = lib.pack_conv_weight(w.to(DEV), None, precision=prec)
+    lib.conv2d(L.view(xd), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bd, L.ACT_RELU, precision=prec,
                stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert torch.allclose(y.cpu(), ref, atol=3e-4, rtol=1e-4), float((y.cpu() - ref).abs().max())
+
+
+@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+def test_conv2d_fused_second_operand_full_size(lib, prec):
+    """The bottleneck global-branch launch at full channel counts: relu(conv3x3(x_l) + conv1x1(t) + b) + resid."""
+    g = torch.Generator().manual_seed(12)
+    B, cl, cg, half, H, W = 2, 128, 384, 192, 64, 64
+    state = torch.randn(B, cl + cg, H, W, generator=g)
+    t = torch.randn(B, half, H, W, generator=g)
+    w1 = torch.randn(cg, cl, 3, 3, generator=g) / (cl * 9) ** 0.5
+    w2 = torch.randn(cg, half, 1, 1, generator=g) / half ** 0.5
+    scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
+    ref = _conv_ref(state[:, :cl], w1, 1, 1, True, False, bias, 1, state[:, cl:], x2=t, w2=w2 * scale[:, None, None, None], scale=scale)
+    sd, td, bd, scd = state.to(DEV), t.to(DEV), bias.to(DEV), scale.to(DEV)
+    out = torch.zeros_like(sd)
+    wp1, wp2 = lib.pack_conv_weight(w1.to(DEV), scd, precision=prec), lib.pack_conv_weight(w2.to(DEV), scd, precision=prec)
+    lib.conv2d(L.view(sd, 0, cl), wp1, L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT, False, bd, L.ACT_RELU, L.view(sd, cl, cg),
+               x2=L.view(td), w2_packed=wp2, precision=prec, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    err = float((out[:, cl:].cpu() - ref).abs().max())
+    assert err < 3e-4, err
 
 
 @pytest.mark.parametrize('hw', FFT_SIZES + [(128, 128), (256, 256), (168, 168)], ids=lambda s: f'{s[0]}x{s[1]}')
@@ -91,7 +114,8 @@ def test_rfft2_irfft2(lib, hw):
     assert torch.allclose(y.cpu(), ref2, atol=tol, rtol=1e-4), float((y.cpu() - ref2).abs().max())
 
 
-def test_fourier_unit_c2_shape(lib):
+@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+def test_fourier_unit_c2_shape(lib, prec):
     """FourierUnit at the BASELINE config-2 shape [8,192,64,64] against the oracle."""
     from oracle import lama_oracle as O
     g = torch.Generator().manual_seed(5)
@@ -104,12 +128,12 @@ def test_fourier_unit_c2_shape(lib):
         ref = x + O.fourier_unit(x, sd, 'fu')
     scale = sd['fu.bn.weight'] / torch.sqrt(sd['fu.bn.running_var'] + 1e-5)
     shift = sd['fu.bn.bias'] - sd['fu.bn.running_mean'] * scale
-    wp = lib.pack_conv_weight(sd['fu.conv_layer.weight'].to(DEV), scale.to(DEV))
+    wp = lib.pack_conv_weight(sd['fu.conv_layer.weight'].to(DEV), scale.to(DEV), precision=prec)
     ws = torch.zeros(lib.fourier_unit_workspace_bytes(B, Cn, h, w) // 4 + 1, device=DEV)
     xd = x.to(DEV)
     y = torch.zeros_like(xd)
     shd = shift.to(DEV)
-    lib.fourier_unit(L.view(xd), wp, shd, L.view(y), B, True, ws, stream=torch.cuda.current_stream().cuda_stream)
+    lib.fourier_unit(L.view(xd), wp, shd, L.view(y), B, True, ws, precision=prec, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert float((y.cpu() - ref).abs().max()) < 1e-4
 

@@ -27,6 +27,8 @@ def timeit(fn, iters=20, warm=3):
 
 
 def main():
+    prec = L.PREC_BF16X3 if (len(sys.argv) > 1 and sys.argv[1] == 'bf16x3') else L.PREC_F32
+    tag = 'bf16x3' if prec == L.PREC_BF16X3 else 'f32'
     lib = L.get_lib()
     dev = 'cuda'
     st = torch.cuda.current_stream().cuda_stream
@@ -41,15 +43,15 @@ def main():
         x = rnd(B, cin, H, W)
         wt = rnd(cin, cout, k, k) if tr else rnd(cout, cin, k, k)
         stride = 2 if tr else stride
-        wp = lib.pack_conv_weight(wt, None, stride=stride, transposed=tr)
+        wp = lib.pack_conv_weight(wt, None, stride=stride, transposed=tr, precision=prec)
         Ho, Wo = (2 * H, 2 * W) if tr else ((H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1)
         y = torch.empty(B, cout, Ho, Wo, device=dev)
         bias = rnd(cout)
         x2 = w2p = None
         if x2c:
-            x2 = rnd(B, x2c, Ho, Wo); w2p = lib.pack_conv_weight(rnd(cout, x2c, 1, 1), None)
+            x2 = rnd(B, x2c, Ho, Wo); w2p = lib.pack_conv_weight(rnd(cout, x2c, 1, 1), None, precision=prec)
         fn = lambda: lib.conv2d(L.view(x), wp, L.view(y), B, k, stride, 1 if tr else k // 2, L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
-                                L.ACT_RELU, None, None if x2 is None else L.view(x2), w2p, stream=st)
+                                L.ACT_RELU, None, None if x2 is None else L.view(x2), w2p, precision=prec, stream=st)
         med, mn = timeit(fn)
         fl = 2.0 * B * Ho * Wo * cout * (cin * k * k / (4 if tr else 1) * (2.25 / 2.25 if not tr else 1) + x2c) if flops is None else flops
         if tr:
@@ -78,17 +80,17 @@ def main():
     res['rfft2_8x192x64x64'] = dict(us=med, us_min=mn, gbps=(x1.numel() + spec.numel()) * 4 / med / 1e3)
     med, mn = timeit(lambda: lib.irfft2(L.view(spec), L.view(x1), L.view(y), B, None, st))
     res['irfft2_add_8x192x64x64'] = dict(us=med, us_min=mn, gbps=(2 * x1.numel() + spec.numel()) * 4 / med / 1e3)
-    wp = lib.pack_conv_weight(rnd(384, 384, 1, 1), None)
+    wp = lib.pack_conv_weight(rnd(384, 384, 1, 1), None, precision=prec)
     bias = rnd(384)
     ws = torch.empty(lib.fourier_unit_workspace_bytes(B, 192, h, w) // 4 + 1, device=dev)
-    med, mn = timeit(lambda: lib.fourier_unit(L.view(x1), wp, bias, L.view(y), B, True, ws, stream=st))
+    med, mn = timeit(lambda: lib.fourier_unit(L.view(x1), wp, bias, L.view(y), B, True, ws, precision=prec, stream=st))
     alg = 2 * x1.numel() * 4 + 384 * 384 * 4 + 384 * 4
     res['fourier_unit_8x192x64x64'] = dict(us=med, us_min=mn, alg_bytes=alg, alg_gbps=alg / med / 1e3, frac_of_8TBs=alg / med / 1e3 / 8000)
     for k in ('rfft2_8x192x64x64', 'irfft2_add_8x192x64x64', 'fourier_unit_8x192x64x64'):
         print(k, res[k], flush=True)
 
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(ROOT, 'gpurun_out', 'kbench.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'gpurun_out', f'kbench_{tag}.json'), 'w') as f:
         json.dump(res, f, indent=1)
 
 
