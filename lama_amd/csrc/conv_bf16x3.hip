@@ -16,9 +16,9 @@
 // TH x TW rectangle; BM = 32 uses 8 waves along N, BN = 256).  K is walked in *stages* of TG taps x
 // 16*KS channels (TG*KS MFMA k-steps of 16):
 //   * weights: pre-split into (hi, lo) bf16 and pre-packed in MFMA A-fragment order by
-//     lama_conv2d_pack_weight, so a stage is ONE contiguous image that the waves stream into LDS with
-//     16-byte global_load_lds DMA (no VGPRs, no VALU) and read back with linear, conflict-free
-//     ds_read_b128; two LDS buffers, the DMA of stage s+1 flies during the MFMAs of stage s;
+//     lama_conv2d_pack_weight, so a stage is ONE contiguous image that is copied L2 -> registers -> LDS with
+//     fully coalesced 16-byte accesses (no VALU) and read back with linear, conflict-free ds_read_b128;
+//     three LDS buffers, the copy runs two to three stages ahead of the MFMAs;
 //   * activations: the input *patch* of a channel chunk (tile + halo, reflection / zero padding
 //     applied, stride-2 columns parity-split) is loaded fp32 from HBM/L2 one chunk ahead into
 //     registers, split into hi/lo bf16 ONCE per element (v_cvt_pk_bf16_f32) and written to LDS as
@@ -33,6 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define CB_THREADS 512
 #define CB_MAX_TAPS 49
@@ -72,7 +73,7 @@ struct CbGeom {
     static constexpr int WAVES_M = (BM >= 64) ? 2 : 1;
     static constexpr int WAVES_N = 8 / WAVES_M;
     static constexpr int BN = WAVES_N * 32;
-    static constexpr int TM = BM / WAVES_M / 32;  // 32-row fragments per wave
+    static constexpr int TM = BM / WAVES_M / 32;  // 32-row fragments per wave (BM = 192 -> 3)
     static constexpr int MF = BM / 32;            // fragments per M tile
 };
 
@@ -97,15 +98,45 @@ __device__ __forceinline__ void cb_split2(float a, float b, unsigned& hi, unsign
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// three ints selected by a (possibly runtime) index without dynamic register indexing (an indexed array would go to scratch)
+struct CbInt3 {
+    int v0, v1, v2;
+    __device__ __forceinline__ void set(int i, int x) {
+        if (i == 0) v0 = x;
+        else if (i == 1) v1 = x;
+        else v2 = x;
+    }
+    __device__ __forceinline__ int get(int i) const { return i == 1 ? v1 : (i == 2 ? v2 : v0); }
+};
+
+template <int V>
+struct CbTag {
+    static constexpr int value = V;
+};
+
+// A / B fragments of one MFMA k-step (16 channels of one tap) for this wave
+template <int TM>
+struct CbFrag {
+    bf16x8 ah[TM], al[TM], bh, bl;
+};
+
 // One K segment: accumulate into acc.
-template <int TG, int KS, int BM, int MAXU>
+//   LDS: three weight-stage buffers (the DMA runs two stages ahead, so the first k-step of stage s+1 can
+//   be fetched into registers BEFORE the barrier that ends stage s) and two patch buffers.
+//   Registers: two fragment sets -- the ds_read_b128 of k-step k+1 are in flight under the MFMAs of k-step k.
+template <int T, int TG, int KS, int BM, int MAXU>
 __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy0, int gx0, int TWlog, char* wbuf0, int wbytes,
                                            char* pbuf0, int pbytes, f32x16 (&acc)[CbGeom<BM>::TM]) {
     using G = CbGeom<BM>;
+    constexpr int NG = T / TG;                      // stages per channel chunk
+    constexpr int NKK = TG * KS;                    // MFMA k-steps per stage
+    constexpr bool XPF = (NG >= 2) && (MAXU <= NG - 1);  // next chunk's patch complete (and behind a barrier) before the
+                                                     // chunk's last stage -> its first B fragment can be prefetched across
     constexpr int NOCT = 2 * KS;                    // channel octets per chunk
     constexpr int BKC = 16 * KS;                    // channels per chunk
-    constexpr int NPIECE = TG * KS * G::MF * 2;     // 1-KiB fragment images per weight stage
+    constexpr int NPIECE = NKK * G::MF * 2;         // 1-KiB fragment images per weight stage
     constexpr int WROUNDS = (NPIECE + 7) / 8;
+    constexpr int WST = NPIECE * 1024;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / G::WAVES_N, wn = wave % G::WAVES_N;
@@ -116,25 +147,28 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
     const int nunits = NPR * NOCT;
     const int plo = NOCT * s.npix * 16;             // byte offset of the lo planes inside a patch buffer
 
-    // per-thread staging units: (patch pixel, channel octet) -> source offset, LDS byte offset
-    int src_off[MAXU], lds_off[MAXU], uq[MAXU];
+    // per-thread staging units: (patch pixel, channel octet) -> element offset in the chunk, LDS byte offset
+    static_assert(MAXU <= 3, "staging units per thread");
+    CbInt3 ubase = {0, 0, 0}, lds_off = {-1, -1, -1}, uq8 = {0, 0, 0}, uvalid = {0, 0, 0};
 #pragma unroll
     for (int i = 0; i < MAXU; ++i) {
         int u = i * CB_THREADS + tid;
-        int so = -1, lo = -1, q = 0;
+        int so = 0, lo = -1, q = 0;
+        int ok = 0;
         if (u < nunits) {
             q = u / NPR;
             int pp = u - q * NPR;
             int py = pp / s.PW, px = pp - py * s.PW;
             int iy = cb_src_coord(gy0 * s.stride + s.dy0 + py, s.H, s.pad_mode);
             int ix = cb_src_coord(gx0 * s.stride + s.dx0 + px, s.W, s.pad_mode);
-            if (iy >= 0 && ix >= 0) so = iy * s.W + ix;
+            if (iy >= 0 && ix >= 0) { so = iy * s.W + ix; ok = 1; }
             int lidx = py * s.PWs + (s.PWh ? (px & 1) * s.PWh + (px >> 1) : px);
             lo = (q * s.npix + lidx) * 16;
         }
-        src_off[i] = so;
-        lds_off[i] = lo;
-        uq[i] = q;
+        ubase.set(i, q * 8 * HW + so);   // always an in-bounds element of the chunk (zero padding is applied at write time)
+        lds_off.set(i, lo);
+        uq8.set(i, q * 8);
+        uvalid.set(i, ok);
     }
     // B-fragment base: this lane's pixel inside the patch, octet plane khalf
     int boff;
@@ -148,94 +182,204 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
 
     const float* xb = s.x + (long long)b * s.bstride;
     const char* wsrc = s.w + (long long)mt * s.mt_bytes;
-    const int S = s.nchunk * s.NG;
-    constexpr int WST = NPIECE * 1024;
+    const int S = s.nchunk * NG;
 
-    float preg[MAXU][8];
-    auto load_patch = [&](int ch) {
+    // Patch staging keeps ONE unit (8 channels of one pixel) per thread in flight: unit u of chunk ch+1 is written to LDS in
+    // stage u of chunk ch and the following unit is requested right after, so a kernel with a large halo (MAXU = 3: stride 2,
+    // 7x7) needs no more staging registers than the bottleneck 3x3 (MAXU = 1).
+    float preg[8];
+    auto usel = [&](const CbInt3& arr, int u) { return MAXU == 1 ? arr.v0 : arr.get(u); };
+    auto load_unit = [&](int ch, int u) {
         const float* xc = xb + (long long)ch * BKC * HW;
         const int crem = s.C - ch * BKC;
+        const int ub = usel(ubase, u);
+        if (crem >= BKC) {  // (uniform) every channel of the chunk exists: unconditional loads, no per-element branches
 #pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            const int so = src_off[i];
-            const int c0 = uq[i] * 8;
+            for (int e = 0; e < 8; ++e) preg[e] = xc[(unsigned)(ub + e * HW)];   // SGPR base + 32-bit lane offset
+        } else {            // channel tail: clamp the address, zero the value (the packed weights are zero there too)
+            const int q8 = usel(uq8, u);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) preg[i][e] = (so >= 0 && c0 + e < crem) ? xc[(long long)(c0 + e) * HW + so] : 0.0f;
-        }
-    };
-    auto write_patch = [&](char* pb) {
-#pragma unroll
-        for (int i = 0; i < MAXU; ++i) {
-            if (lds_off[i] >= 0) {
-                uint4 h, l;
-                cb_split2(preg[i][0], preg[i][1], h.x, l.x);
-                cb_split2(preg[i][2], preg[i][3], h.y, l.y);
-                cb_split2(preg[i][4], preg[i][5], h.z, l.z);
-                cb_split2(preg[i][6], preg[i][7], h.w, l.w);
-                *reinterpret_cast<uint4*>(pb + lds_off[i]) = h;
-                *reinterpret_cast<uint4*>(pb + plo + lds_off[i]) = l;
+            for (int e = 0; e < 8; ++e) {
+                int c = q8 + e;
+                int back = c < crem ? 0 : (c - (crem - 1)) * HW;
+                float v = xc[(unsigned)(ub + e * HW - back)];
+                preg[e] = c < crem ? v : 0.0f;
             }
         }
     };
-    auto stage_weights = [&](int st, char* wb) {
-        const char* g = wsrc + (long long)st * WST;
+    auto write_unit = [&](char* pb, int u) {
+        const int lo = usel(lds_off, u);
+        if (lo >= 0) {
+            unsigned hh[4], ll[4];
 #pragma unroll
-        for (int r = 0; r < WROUNDS; ++r) {
-            int piece = r * 8 + wave;
-            if (piece < NPIECE)
-                __builtin_amdgcn_global_load_lds(reinterpret_cast<const unsigned*>(g + piece * 1024 + lane * 16), LAMA_LDS_PTR(wb + piece * 1024),
-                                                 16, 0, 0);
+            for (int e = 0; e < 4; ++e) cb_split2(preg[2 * e], preg[2 * e + 1], hh[e], ll[e]);
+            u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+            if (!usel(uvalid, u)) { h = u32x4{0, 0, 0, 0}; l = h; }   // zero padding
+            *reinterpret_cast<u32x4*>(pb + lo) = h;
+            *reinterpret_cast<u32x4*>(pb + plo + lo) = l;
         }
     };
-
-    // prologue: stage 0 weights, chunk 0 patch, chunk 1 in flight
-    stage_weights(0, wbuf0);
-    load_patch(0);
-    write_patch(pbuf0);
-    if (s.nchunk > 1) load_patch(1);
-    __syncthreads();
-
-    int st = 0;
-    for (int ch = 0; ch < s.nchunk; ++ch) {
-        const char* pb = pbuf0 + (ch & 1) * pbytes;
-        for (int g = 0; g < s.NG; ++g, ++st) {
-            const char* wb = wbuf0 + (st & 1) * wbytes;
-            if (st + 1 < S) stage_weights(st + 1, wbuf0 + ((st + 1) & 1) * wbytes);
-            if (g == s.NG - 1 && ch + 1 < s.nchunk) {
-                // next chunk's patch (loaded a chunk ago) -> the other buffer; then start the chunk after
-                write_patch(pbuf0 + ((ch + 1) & 1) * pbytes);
-                if (ch + 2 < s.nchunk) load_patch(ch + 2);
+    // stage g of chunk ch: write the unit(s) of chunk ch+1 that belong to this stage, keep the next one in flight
+    auto stage_patch = [&](int ch, int g, char* pbn) {
+        if (ch + 1 >= s.nchunk) return;
+        if constexpr (NG >= MAXU) {
+            if (g < MAXU) {
+                write_unit(pbn, g);
+                if (g + 1 < MAXU) load_unit(ch + 1, g + 1);
+                else if (ch + 2 < s.nchunk) load_unit(ch + 2, 0);
             }
+        } else {   // fewer stages than units (only tiny-M kernels): the rest synchronously in stage 0
+            if (g == 0) {
 #pragma unroll
-            for (int tgi = 0; tgi < TG; ++tgi) {
-                const int toff = s.tapoff[g * TG + tgi] * 16;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const int kk = tgi * KS + ks;
-                    const char* bp = pb + (ks * 2 * s.npix) * 16 + boff + toff;
-                    bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-                    bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + plo);
-#pragma unroll
-                    for (int i = 0; i < G::TM; ++i) {
-                        const char* ap = wb + (kk * G::MF * 2 + i * 2) * 1024 + aoff;
-                        bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-                        bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 1024);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i], 0, 0, 0);
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i], 0, 0, 0);
-                    }
+                for (int u = 0; u < MAXU; ++u) {
+                    write_unit(pbn, u);
+                    if (u + 1 < MAXU) load_unit(ch + 1, u + 1);
+                    else if (ch + 2 < s.nchunk) load_unit(ch + 2, 0);
                 }
             }
-            __syncthreads();
+        }
+    };
+    // weight stage st: global (L2-resident packed image) -> registers; written to LDS a stage later.  Plain loads + ds_write
+    // instead of global_load_lds DMA: with a DMA in flight hipcc degrades every s_waitcnt to lgkmcnt(0)/vmcnt(0), which
+    // serialises the ds_read prefetch below; 16 B per lane per round keeps the loads fully coalesced.
+    u32x4 wreg[WROUNDS];
+    constexpr int WITEMS = NPIECE * 64;   // 16-byte items per stage image
+    auto load_w = [&](int st) {
+        const u32x4* g = reinterpret_cast<const u32x4*>(wsrc + (long long)st * WST);
+#pragma unroll
+        for (int r = 0; r < WROUNDS; ++r) {
+            int idx = r * CB_THREADS + tid;
+            if ((r + 1) * CB_THREADS > WITEMS) idx = idx < WITEMS ? idx : WITEMS - 1;   // partial last round: clamp, never branch
+            wreg[r] = g[idx];
+        }
+    };
+    auto write_w = [&](char* wb) {
+        u32x4* d = reinterpret_cast<u32x4*>(wb);
+#pragma unroll
+        for (int r = 0; r < WROUNDS; ++r) {
+            int idx = r * CB_THREADS + tid;
+            if ((r + 1) * CB_THREADS <= WITEMS || idx < WITEMS) d[idx] = wreg[r];
+        }
+    };
+    using Frag = CbFrag<G::TM>;
+    auto read_a = [&](Frag& f, const char* wb, int kk) {
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) {
+            const char* ap = wb + (kk * G::MF * 2 + i * 2) * 1024 + aoff;
+            f.ah[i] = *reinterpret_cast<const bf16x8*>(ap);
+            f.al[i] = *reinterpret_cast<const bf16x8*>(ap + 1024);
+        }
+    };
+    // LDS offset of tap (g*TG + tgi) = tgoff[tgi] + g * grow: one kernel row (or the whole transposed-class tap list) per stage,
+    // so the stage loop needs no scalar loads (an SMEM load in flight would force lgkmcnt(0) on every ds_read wait)
+    int tgoff[TG];
+#pragma unroll
+    for (int i = 0; i < TG; ++i) tgoff[i] = s.tapoff[i] * 16;
+    const int grow = NG > 1 ? (s.tapoff[TG] - s.tapoff[0]) * 16 : 0;
+    auto read_b = [&](Frag& f, const char* pb, int g, int tgi, int ks) {
+        const char* bp = pb + (ks * 2 * s.npix) * 16 + tgoff[tgi] + g * grow + boff;
+        f.bh = *reinterpret_cast<const bf16x8*>(bp);
+        f.bl = *reinterpret_cast<const bf16x8*>(bp + plo);
+    };
+
+    // prologue: weight stages 0 and 1 and the chunk-0 patch in LDS; stage 2 / chunk 1 in flight to registers
+    load_w(0);
+    load_unit(0, 0);
+    write_w(wbuf0);
+    if (S > 1) { load_w(1); write_w(wbuf0 + wbytes); }
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+        write_unit(pbuf0, u);
+        if (u + 1 < MAXU) load_unit(0, u + 1);
+    }
+    if (S > 2) load_w(2);
+    if (s.nchunk > 1) load_unit(1, 0);
+    __syncthreads();
+    Frag fr[2];   // fragment sets, indexed with compile-time parity only (two k-steps in flight, no register copies)
+    read_a(fr[0], wbuf0, 0);
+    read_b(fr[0], pbuf0, 0, 0, 0);
+
+    int st = 0, wi = 0;  // wi = st % 3
+    // one channel chunk = NG stages = NG*NKK k-steps; PAR = parity of the fragment set holding its first k-step
+    // FLAT: stages of a chunk fully unrolled and the fragment-set parity carried at compile time (the bottleneck kernels);
+    // otherwise (7x7 kernels, big staging footprints) a rolled stage loop that realigns the parity with one register copy
+    // per stage, which keeps code size and register pressure down.
+    constexpr bool FLAT = (NG <= 3) && (MAXU == 1);
+    auto stage = [&](int ch, int g, auto par_tag) {
+        constexpr int PAR = decltype(par_tag)::value;
+        const char* pb = pbuf0 + (ch & 1) * pbytes;
+        char* pbn = pbuf0 + ((ch + 1) & 1) * pbytes;
+        const char* wb = wbuf0 + wi * wbytes;
+        const int wi1 = wi == 2 ? 0 : wi + 1, wi2 = wi1 == 2 ? 0 : wi1 + 1;
+        const char* wbn = wbuf0 + wi1 * wbytes;
+        stage_patch(ch, g, pbn);
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            Frag& cur = fr[(PAR + kk) & 1];
+            Frag& nxt = fr[(PAR + kk + 1) & 1];
+            if (kk + 1 < NKK) {
+                const int tgi = (kk + 1) / KS, ks = (kk + 1) % KS;
+                read_a(nxt, wb, kk + 1);
+                read_b(nxt, pb, g, tgi, ks);
+            } else {
+                if (st + 1 < S) {
+                    // first k-step of the next stage: its weights were written before the previous barrier
+                    read_a(nxt, wbn, 0);
+                    if (g + 1 < NG) read_b(nxt, pb, g + 1, 0, 0);
+                    else if (XPF) read_b(nxt, pbn, 0, 0, 0);   // next chunk's patch is complete and visible
+                }
+                // stage st+2 (in registers since the end of stage st-1) -> the buffer stage st-1 was read from
+                if (st + 2 < S) write_w(wbuf0 + wi2 * wbytes);
+            }
+            // pin the order: the ds_reads of the NEXT k-step are issued before this k-step's MFMAs and are only
+            // waited for after them (hipcc otherwise sinks the reads next to their use and exposes the LDS latency)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh, acc[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (st + 3 < S) load_w(st + 3);   // registers are free again: fetch three stages ahead
+        __syncthreads();
+        if (!XPF && g == NG - 1 && st + 1 < S) read_b(fr[(PAR + NKK) & 1], pbn, 0, 0, 0);   // chunk boundary: new patch visible only now
+        wi = wi1;
+        ++st;
+    };
+    if constexpr (FLAT) {
+        // one chunk = NG*NKK k-steps; an odd count flips the parity for the next chunk -> unroll two chunks
+        auto chunk = [&](int ch, auto par_tag) {
+            constexpr int PAR = decltype(par_tag)::value;
+            stage(ch, 0, CbTag<PAR & 1>{});
+            if constexpr (NG > 1) stage(ch, 1, CbTag<(PAR + NKK) & 1>{});
+            if constexpr (NG > 2) stage(ch, 2, CbTag<(PAR + 2 * NKK) & 1>{});
+        };
+        if constexpr ((NG * NKK) % 2 == 0) {
+            for (int ch = 0; ch < s.nchunk; ++ch) chunk(ch, CbTag<0>{});
+        } else {
+            for (int ch = 0; ch < s.nchunk; ch += 2) {
+                chunk(ch, CbTag<0>{});
+                if (ch + 1 < s.nchunk) chunk(ch + 1, CbTag<1>{});
+            }
+        }
+    } else {
+        for (int ch = 0; ch < s.nchunk; ++ch) {
+#pragma unroll 1
+            for (int g = 0; g < NG; ++g) {
+                stage(ch, g, CbTag<0>{});
+                if constexpr (NKK % 2 == 1) fr[0] = fr[1];   // realign: the next stage's first k-step was fetched into set 1
+            }
         }
     }
 }
 
-template <int TG1, int KS1, int TG2, int KS2, int BM, int MAXU>
+template <int T1, int TG1, int KS1, int T2, int TG2, int KS2, int BM, int MAXU>
 __global__ __launch_bounds__(CB_THREADS) void conv_bf16x3_kernel(CbParams p) {
     using G = CbGeom<BM>;
     char* wbuf0 = lama_smem;
-    char* pbuf0 = lama_smem + 2 * p.wbytes;
+    char* pbuf0 = lama_smem + 3 * p.wbytes;
 
     const int L = lama_xcd_remap(blockIdx.x, gridDim.x);
     const int mt = L % p.MT;
@@ -253,8 +397,8 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bf16x3_kernel(CbParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    cb_segment<TG1, KS1, BM, MAXU>(p.s1, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
-    if constexpr (TG2 > 0) cb_segment<TG2, KS2, BM, MAXU>(p.s2, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
+    cb_segment<T1, TG1, KS1, BM, MAXU>(p.s1, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
+    if constexpr (TG2 > 0) cb_segment<T2, TG2, KS2, BM, MAXU>(p.s2, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
 
     // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -360,7 +504,14 @@ struct CbPlan {
     long long total_bytes;
 };
 
-int cb_pick_bm(int M) { return M > 64 ? 128 : (M > 32 ? 64 : 32); }
+// M-tile height.  192 when it divides the channel count with less per-CU work than 128 (M = 192: one tile instead of two
+// 25%-empty ones; M = 384: 2 x 192 halves the patch re-reads of 3 x 128); 7x7 kernels keep their 7-tap weight stages <= 64 rows.
+int cb_pick_bm(int M, int T, int stride) {
+    if (M <= 32 && stride == 1) return 32;   // (a 256-pixel stride-2 tile would not leave room for two patch buffers)
+    if (M <= 64 || T == 49) return 64;
+    if (M % 192 == 0 && M % 128 != 0) return 192;
+    return 128;
+}
 
 bool cb_stage_shape(int T, int* TG, int* KS) {
     switch (T) {
@@ -373,8 +524,8 @@ bool cb_stage_shape(int T, int* TG, int* KS) {
     return false;
 }
 
-bool cb_make_plan(int cout, int cin, int kh, int kw, int stride, int pad, int transposed, CbPlan* pl) {
-    pl->BM = cb_pick_bm(cout);
+bool cb_make_plan(int cout, int cin, int kh, int kw, int stride, int pad, int transposed, CbPlan* pl, int force_bm = 0) {
+    pl->BM = force_bm ? force_bm : cb_pick_bm(cout, transposed ? 4 : kh * kw, transposed ? 1 : stride);
     pl->MT = lama_ceil_div(cout, pl->BM);
     if (transposed) {
         if (kh != 3 || kw != 3 || stride != 2 || pad != 1) return false;
@@ -462,39 +613,39 @@ int cb_fill_seg(CbSeg* s, const lama_tensor& x, const char* w, const CbPlan& pl,
     return s->PH * s->PW * 2 * pl.KS[cls];
 }
 
-template <int TG1, int KS1, int TG2, int KS2, int BM>
+template <int T1, int TG1, int KS1, int T2, int TG2, int KS2, int BM>
 int cb_launch_u(hipStream_t st, const CbParams& p, int maxu, int grid, size_t shmem) {
-    if (maxu <= 1) hipLaunchKernelGGL((conv_bf16x3_kernel<TG1, KS1, TG2, KS2, BM, 1>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
-    else if (maxu <= 3) hipLaunchKernelGGL((conv_bf16x3_kernel<TG1, KS1, TG2, KS2, BM, 3>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
-    else if (maxu <= 5) hipLaunchKernelGGL((conv_bf16x3_kernel<TG1, KS1, TG2, KS2, BM, 5>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
+    if (maxu <= 1) hipLaunchKernelGGL((conv_bf16x3_kernel<T1, TG1, KS1, T2, TG2, KS2, BM, 1>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
+    else if (maxu <= 3) hipLaunchKernelGGL((conv_bf16x3_kernel<T1, TG1, KS1, T2, TG2, KS2, BM, 3>), dim3(grid), dim3(CB_THREADS), shmem, st, p);
     else return LAMA_ERR_UNSUPPORTED;
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }
 
-template <int TG1, int KS1, int TG2, int KS2>
+template <int T1, int TG1, int KS1, int T2, int TG2, int KS2>
 int cb_launch_bm(hipStream_t st, const CbParams& p, int BM, int maxu, int grid, size_t shmem) {
     switch (BM) {
-        case 128: return cb_launch_u<TG1, KS1, TG2, KS2, 128>(st, p, maxu, grid, shmem);
-        case 64: return cb_launch_u<TG1, KS1, TG2, KS2, 64>(st, p, maxu, grid, shmem);
-        case 32: return cb_launch_u<TG1, KS1, TG2, KS2, 32>(st, p, maxu, grid, shmem);
+        case 192: return cb_launch_u<T1, TG1, KS1, T2, TG2, KS2, 192>(st, p, maxu, grid, shmem);
+        case 128: return cb_launch_u<T1, TG1, KS1, T2, TG2, KS2, 128>(st, p, maxu, grid, shmem);
+        case 64: return cb_launch_u<T1, TG1, KS1, T2, TG2, KS2, 64>(st, p, maxu, grid, shmem);
+        case 32: return cb_launch_u<T1, TG1, KS1, T2, TG2, KS2, 32>(st, p, maxu, grid, shmem);
     }
     return LAMA_ERR_UNSUPPORTED;
 }
 
-int cb_launch(hipStream_t st, const CbParams& p, int TG1, int KS1, int TG2, int KS2, int BM, int maxu) {
-    const size_t shmem = 2 * (size_t)p.wbytes + 2 * (size_t)p.pbytes;
+int cb_launch(hipStream_t st, const CbParams& p, int T1, int T2, int BM, int maxu) {
+    const size_t shmem = 3 * (size_t)p.wbytes + 2 * (size_t)p.pbytes;
     if (shmem > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
     const int grid = p.B * p.tiles_x * p.tiles_y * p.MT;
     if (grid <= 0) return LAMA_OK;
-#define CB_CASE(t1, k1, t2, k2) \
-    if (TG1 == t1 && KS1 == k1 && TG2 == t2 && KS2 == k2) return cb_launch_bm<t1, k1, t2, k2>(st, p, BM, maxu, grid, shmem);
-    CB_CASE(3, 1, 0, 0)
-    CB_CASE(3, 1, 1, 2)
-    CB_CASE(1, 2, 0, 0)
-    CB_CASE(7, 1, 0, 0)
-    CB_CASE(2, 1, 0, 0)
-    CB_CASE(4, 1, 0, 0)
+#define CB_CASE(t1, g1, k1, t2, g2, k2) \
+    if (T1 == t1 && T2 == t2) return cb_launch_bm<t1, g1, k1, t2, g2, k2>(st, p, BM, maxu, grid, shmem);
+    CB_CASE(9, 3, 1, 0, 0, 0)
+    CB_CASE(9, 3, 1, 1, 1, 2)
+    CB_CASE(1, 1, 2, 0, 0, 0)
+    CB_CASE(49, 7, 1, 0, 0, 0)
+    CB_CASE(2, 2, 1, 0, 0, 0)
+    CB_CASE(4, 4, 1, 0, 0, 0)
 #undef CB_CASE
     return LAMA_ERR_UNSUPPORTED;
 }
@@ -547,6 +698,8 @@ int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, in
     CbPlan pl2;
     if (has2 && (!cb_make_plan(cout, a->x2.C, 1, 1, 1, 0, 0, &pl2) || pl2.BM != pl.BM)) return LAMA_ERR_UNSUPPORTED;
     const int BN = pl.BM >= 64 ? 128 : 256;
+    if ((long long)a->x.C * a->x.H * a->x.W >= (1ll << 31) || (has2 && (long long)a->x2.C * a->x2.H * a->x2.W >= (1ll << 31)))
+        return LAMA_ERR_UNSUPPORTED;   // 32-bit element offsets inside one image
 
     for (int cls = 0; cls < pl.nseg; ++cls) {
         CbParams p;
@@ -592,7 +745,7 @@ int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, in
         }
         p.wbytes = (int)wbytes;
         p.pbytes = (int)pbytes;
-        int rc = cb_launch(stream, p, pl.TG[cls], pl.KS[cls], TG2, KS2, pl.BM, lama_ceil_div(units, CB_THREADS));
+        int rc = cb_launch(stream, p, pl.T[cls], has2 ? 1 : 0, pl.BM, lama_ceil_div(units, CB_THREADS));
         if (rc != LAMA_OK) return rc;
     }
     return LAMA_OK;

@@ -146,7 +146,7 @@ class _HipModule(nn.Module):
         for m in self.modules():
             if isinstance(m, _HipModule):
                 m.precision = precision
-                m._packed = None
+        self._invalidate()          # packed weights and captured graphs belong to the old precision
         return self
 
     def train(self, mode: bool = True):
