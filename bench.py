@@ -210,6 +210,8 @@ def main():
     kern = {}
     if rank == 0:
         model.generator.use_graph = False
+        model.generator.overlap_streams = False     # per-kernel events need every launch on the current stream
+        model.generator._plans = {}
         step()
         torch.cuda.synchronize()
         timer.on = True
@@ -243,6 +245,7 @@ def main():
     if rank == 0 and world == 1 and precision != L.PREC_F32 and not args.no_f32_leg:
         model.generator.set_precision(L.PREC_F32)
         model.generator.use_graph = not args.no_graph
+        model.generator.overlap_streams = True
         for _ in range(2):
             step()
         torch.cuda.synchronize()

@@ -40,6 +40,11 @@ __device__ __forceinline__ int lama_xcd_remap(int orig, int nwg) {
 #define LAMA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #endif
 
+// keep a value live without cost (timing ablations must not let the compiler delete the work that produced it)
+#ifndef LAMA_KEEP_LIVE
+#define LAMA_KEEP_LIVE(x) asm volatile("" ::"v"(x))
+#endif
+
 // bf16x3 convolution back end (conv_bf16x3.hip), reached through lama_conv2d_* with LAMA_PREC_BF16X3
 int64_t lama_cb_packed_weight_bytes(int cout, int cin, int kh, int kw, int stride, int transposed);
 int lama_cb_pack_weight(hipStream_t stream, const float* w, const float* scale, int cout, int cin, int kh, int kw, int stride,

@@ -28,6 +28,7 @@
 // A second K segment (1x1 over x2) chains into the same accumulators:
 //   out_xg = convl2g(x_l) + convg2g.conv2(x1 + fu(x1))  (ffc.py:161,223) + BN shift + ReLU + residual.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -42,8 +43,8 @@ struct CbSeg {
     const float* x;
     long long bstride;
     int C, H, W;
-    const char* w;       // packed stage images of this sub-convolution; M-tile mt starts at w + mt*mt_bytes
-    long long mt_bytes;
+    const char* w;       // packed weights of this sub-convolution: [stage][k-step][32-row fragment F][hi|lo][lane][8 x bf16]
+    int mft;             // fragments per k-step = ceil(M / 32); a k-step image is mft * 2048 bytes
     int nchunk, NG;      // channel chunks (16*KS channels each), tap groups (TG taps each) per chunk
     int stride, pad_mode;
     int dy0, dx0;        // patch origin relative to (gy*stride, gx*stride)
@@ -70,7 +71,7 @@ struct CbParams {
 
 template <int BM>
 struct CbGeom {
-    static constexpr int WAVES_M = (BM >= 64) ? 2 : 1;
+    static constexpr int WAVES_M = (BM >= 128) ? 2 : 1;   // BM <= 64: all 8 waves along N (256 pixels), 64 rows -> TM = 2
     static constexpr int WAVES_N = 8 / WAVES_M;
     static constexpr int BN = WAVES_N * 32;
     static constexpr int TM = BM / WAVES_M / 32;  // 32-row fragments per wave (BM = 192 -> 3)
@@ -124,7 +125,9 @@ struct CbFrag {
 //   LDS: three weight-stage buffers (the DMA runs two stages ahead, so the first k-step of stage s+1 can
 //   be fetched into registers BEFORE the barrier that ends stage s) and two patch buffers.
 //   Registers: two fragment sets -- the ds_read_b128 of k-step k+1 are in flight under the MFMAs of k-step k.
-template <int T, int TG, int KS, int BM, int MAXU>
+// ABL: timing-only ablations selected by the environment variable LAMA_CB_ABLATE for the profiling tools (results are
+// WRONG for ABL != 0): bit 0 = no MFMA, bit 1 = no fragment ds_reads in the loop, bit 2 = no staging, bit 3 = no barriers.
+template <int T, int TG, int KS, int BM, int MAXU, int ABL = 0>
 __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy0, int gx0, int TWlog, char* wbuf0, int wbytes,
                                            char* pbuf0, int pbytes, f32x16 (&acc)[CbGeom<BM>::TM]) {
     using G = CbGeom<BM>;
@@ -181,21 +184,21 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
     const int aoff = (wm * G::TM * 2) * 1024 + lane * 16;  // A fragments of this wave inside a k-step image
 
     const float* xb = s.x + (long long)b * s.bstride;
-    const char* wsrc = s.w + (long long)mt * s.mt_bytes;
     const int S = s.nchunk * NG;
 
     // Patch staging keeps ONE unit (8 channels of one pixel) per thread in flight: unit u of chunk ch+1 is written to LDS in
     // stage u of chunk ch and the following unit is requested right after, so a kernel with a large halo (MAXU = 3: stride 2,
     // 7x7) needs no more staging registers than the bottleneck 3x3 (MAXU = 1).
-    float preg[8];
+    constexpr int UF = (NG >= MAXU) ? 1 : MAXU;   // units in flight: all of them when a chunk has fewer stages than units
+    float preg[UF][8];
     auto usel = [&](const CbInt3& arr, int u) { return MAXU == 1 ? arr.v0 : arr.get(u); };
-    auto load_unit = [&](int ch, int u) {
+    auto load_unit = [&](int ch, int u, int slot = 0) {
         const float* xc = xb + (long long)ch * BKC * HW;
         const int crem = s.C - ch * BKC;
         const int ub = usel(ubase, u);
         if (crem >= BKC) {  // (uniform) every channel of the chunk exists: unconditional loads, no per-element branches
 #pragma unroll
-            for (int e = 0; e < 8; ++e) preg[e] = xc[(unsigned)(ub + e * HW)];   // SGPR base + 32-bit lane offset
+            for (int e = 0; e < 8; ++e) preg[slot][e] = xc[(unsigned)(ub + e * HW)];   // SGPR base + 32-bit lane offset
         } else {            // channel tail: clamp the address, zero the value (the packed weights are zero there too)
             const int q8 = usel(uq8, u);
 #pragma unroll
@@ -203,16 +206,16 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
                 int c = q8 + e;
                 int back = c < crem ? 0 : (c - (crem - 1)) * HW;
                 float v = xc[(unsigned)(ub + e * HW - back)];
-                preg[e] = c < crem ? v : 0.0f;
+                preg[slot][e] = c < crem ? v : 0.0f;
             }
         }
     };
-    auto write_unit = [&](char* pb, int u) {
+    auto write_unit = [&](char* pb, int u, int slot = 0) {
         const int lo = usel(lds_off, u);
         if (lo >= 0) {
             unsigned hh[4], ll[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) cb_split2(preg[2 * e], preg[2 * e + 1], hh[e], ll[e]);
+            for (int e = 0; e < 4; ++e) cb_split2(preg[slot][2 * e], preg[slot][2 * e + 1], hh[e], ll[e]);
             u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
             if (!usel(uvalid, u)) { h = u32x4{0, 0, 0, 0}; l = h; }   // zero padding
             *reinterpret_cast<u32x4*>(pb + lo) = h;
@@ -220,21 +223,29 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
         }
     };
     // stage g of chunk ch: write the unit(s) of chunk ch+1 that belong to this stage, keep the next one in flight
+    // With a single unit and >= 3 stages per chunk the two waves of a SIMD stage their unit in DIFFERENT stages (waves 0-3 in
+    // stage 0, waves 4-7 in stage 1), so the split / address VALU work of one runs under the MFMAs of the other.
+    const int gskew = (MAXU == 1 && NG >= 3) ? (wave >> 2) : 0;
     auto stage_patch = [&](int ch, int g, char* pbn) {
         if (ch + 1 >= s.nchunk) return;
         if constexpr (NG >= MAXU) {
-            if (g < MAXU) {
+            if (MAXU == 1) {
+                if (g == gskew) {
+                    write_unit(pbn, 0);
+                    if (ch + 2 < s.nchunk) load_unit(ch + 2, 0);
+                }
+            } else if (g < MAXU) {
                 write_unit(pbn, g);
                 if (g + 1 < MAXU) load_unit(ch + 1, g + 1);
                 else if (ch + 2 < s.nchunk) load_unit(ch + 2, 0);
             }
-        } else {   // fewer stages than units (only tiny-M kernels): the rest synchronously in stage 0
+        } else {   // fewer stages than units: every unit has its own register slot and all are written / reloaded in stage 0
             if (g == 0) {
 #pragma unroll
-                for (int u = 0; u < MAXU; ++u) {
-                    write_unit(pbn, u);
-                    if (u + 1 < MAXU) load_unit(ch + 1, u + 1);
-                    else if (ch + 2 < s.nchunk) load_unit(ch + 2, 0);
+                for (int u = 0; u < MAXU; ++u) write_unit(pbn, u, u);
+                if (ch + 2 < s.nchunk) {
+#pragma unroll
+                    for (int u = 0; u < MAXU; ++u) load_unit(ch + 2, u, u);
                 }
             }
         }
@@ -244,13 +255,18 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
     // serialises the ds_read prefetch below; 16 B per lane per round keeps the loads fully coalesced.
     u32x4 wreg[WROUNDS];
     constexpr int WITEMS = NPIECE * 64;   // 16-byte items per stage image
+    // The packed layout does not depend on the M-tile height: this workgroup copies fragments [mt*MF, mt*MF + MF) of each
+    // k-step (one contiguous MF*2 KiB run per k-step; fragments past the last one are clamped, their rows are never stored).
     auto load_w = [&](int st) {
-        const u32x4* g = reinterpret_cast<const u32x4*>(wsrc + (long long)st * WST);
+        const u32x4* g = reinterpret_cast<const u32x4*>(s.w) + (long long)st * NKK * s.mft * 128;
 #pragma unroll
         for (int r = 0; r < WROUNDS; ++r) {
             int idx = r * CB_THREADS + tid;
             if ((r + 1) * CB_THREADS > WITEMS) idx = idx < WITEMS ? idx : WITEMS - 1;   // partial last round: clamp, never branch
-            wreg[r] = g[idx];
+            const int kk = idx / (G::MF * 128), rem = idx - kk * (G::MF * 128);
+            int F = mt * G::MF + (rem >> 7);
+            F = F < s.mft ? F : s.mft - 1;
+            wreg[r] = g[(kk * s.mft + F) * 128 + (rem & 127)];
         }
     };
     auto write_w = [&](char* wb) {
@@ -286,14 +302,21 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
     load_w(0);
     load_unit(0, 0);
     write_w(wbuf0);
-    if (S > 1) { load_w(1); write_w(wbuf0 + wbytes); }
+    if (S > 1) load_w(1);               // in flight while the first patch unit is converted
 #pragma unroll
     for (int u = 0; u < MAXU; ++u) {
         write_unit(pbuf0, u);
         if (u + 1 < MAXU) load_unit(0, u + 1);
     }
+    if (s.nchunk > 1) {
+        if constexpr (UF == 1) load_unit(1, 0);
+        else {
+#pragma unroll
+            for (int u = 0; u < MAXU; ++u) load_unit(1, u, u);
+        }
+    }
+    if (S > 1) write_w(wbuf0 + wbytes);
     if (S > 2) load_w(2);
-    if (s.nchunk > 1) load_unit(1, 0);
     __syncthreads();
     Frag fr[2];   // fragment sets, indexed with compile-time parity only (two k-steps in flight, no register copies)
     read_a(fr[0], wbuf0, 0);
@@ -312,12 +335,15 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
         const char* wb = wbuf0 + wi * wbytes;
         const int wi1 = wi == 2 ? 0 : wi + 1, wi2 = wi1 == 2 ? 0 : wi1 + 1;
         const char* wbn = wbuf0 + wi1 * wbytes;
-        stage_patch(ch, g, pbn);
+        if constexpr (!(ABL & 4)) stage_patch(ch, g, pbn);
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
             Frag& cur = fr[(PAR + kk) & 1];
             Frag& nxt = fr[(PAR + kk + 1) & 1];
-            if (kk + 1 < NKK) {
+            if constexpr (ABL & 2) {
+                if (kk + 1 == NKK && !(ABL & 4) && st + 2 < S) write_w(wbuf0 + wi2 * wbytes);
+                nxt = cur;
+            } else if (kk + 1 < NKK) {
                 const int tgi = (kk + 1) / KS, ks = (kk + 1) % KS;
                 read_a(nxt, wb, kk + 1);
                 read_b(nxt, pb, g, tgi, ks);
@@ -329,21 +355,26 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
                     else if (XPF) read_b(nxt, pbn, 0, 0, 0);   // next chunk's patch is complete and visible
                 }
                 // stage st+2 (in registers since the end of stage st-1) -> the buffer stage st-1 was read from
-                if (st + 2 < S) write_w(wbuf0 + wi2 * wbytes);
+                if (!(ABL & 4) && st + 2 < S) write_w(wbuf0 + wi2 * wbytes);
             }
             // pin the order: the ds_reads of the NEXT k-step are issued before this k-step's MFMAs and are only
             // waited for after them (hipcc otherwise sinks the reads next to their use and exposes the LDS latency)
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ABL & 1) {
 #pragma unroll
-            for (int i = 0; i < G::TM; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh, acc[i], 0, 0, 0);
+                for (int i = 0; i < G::TM; ++i) { LAMA_KEEP_LIVE(cur.ah[i]); LAMA_KEEP_LIVE(cur.al[i]); LAMA_KEEP_LIVE(cur.bh); LAMA_KEEP_LIVE(cur.bl); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < G::TM; ++i) {
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bh, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.ah[i], cur.bl, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.al[i], cur.bh, acc[i], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (st + 3 < S) load_w(st + 3);   // registers are free again: fetch three stages ahead
-        __syncthreads();
+        if (!(ABL & 4) && st + 3 < S) load_w(st + 3);   // registers are free again: fetch three stages ahead
+        if constexpr (!(ABL & 8)) __syncthreads();
         if (!XPF && g == NG - 1 && st + 1 < S) read_b(fr[(PAR + NKK) & 1], pbn, 0, 0, 0);   // chunk boundary: new patch visible only now
         wi = wi1;
         ++st;
@@ -375,7 +406,7 @@ __device__ __forceinline__ void cb_segment(const CbSeg& s, int mt, int b, int gy
     }
 }
 
-template <int T1, int TG1, int KS1, int T2, int TG2, int KS2, int BM, int MAXU>
+template <int T1, int TG1, int KS1, int T2, int TG2, int KS2, int BM, int MAXU, int ABL = 0>
 __global__ __launch_bounds__(CB_THREADS) void conv_bf16x3_kernel(CbParams p) {
     using G = CbGeom<BM>;
     char* wbuf0 = lama_smem;
@@ -397,7 +428,7 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bf16x3_kernel(CbParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
 
-    cb_segment<T1, TG1, KS1, BM, MAXU>(p.s1, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
+    cb_segment<T1, TG1, KS1, BM, MAXU, ABL>(p.s1, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
     if constexpr (TG2 > 0) cb_segment<T2, TG2, KS2, BM, MAXU>(p.s2, mt, b, gy0, gx0, p.TWlog, wbuf0, p.wbytes, pbuf0, p.pbytes, acc);
 
     // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
@@ -428,38 +459,35 @@ __global__ __launch_bounds__(CB_THREADS) void conv_bf16x3_kernel(CbParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing: reference layout fp32 -> per (M tile, stage) images of (hi, lo) bf16 A fragments
-//   image of one stage: [k-step kk = tgi*KS + ks][fragment mf][hi|lo][lane][8 x bf16]
-//   lane l of fragment mf holds output channel m = mt*BM + mf*32 + (l&31),
+// weight packing: reference layout fp32 -> [stage][k-step kk = tgi*KS + ks][32-row fragment F][hi|lo][lane][8 x bf16]
+//   (hi, lo) bf16 A fragments; independent of the M-tile height the launch later picks:
+//   lane l of fragment F holds output channel m = F*32 + (l&31),
 //   input channels c = ch*16*KS + ks*16 + 8*(l>>5) + e  (e = 0..7), tap t = g*TG + tgi
 // ------------------------------------------------------------------------------------------------
 struct CbPackParams {
     const float* w;
     const float* scale;
     char* dst;
-    int M, C, BM, MT, TG, KS, NG, nchunk;
+    int M, C, MFT, TG, KS, NG, nchunk;
     int kh, kw, transposed;
     int tap_ky[CB_MAX_TAPS], tap_kx[CB_MAX_TAPS];
 };
 
 __global__ void conv_bf16x3_pack_kernel(CbPackParams p) {
-    const int MF = p.BM / 32;
-    const long long per_stage = (long long)p.TG * p.KS * MF * 64;  // (kk, mf, lane) items; each writes hi and lo 16 B
-    const long long total = (long long)p.MT * p.nchunk * p.NG * per_stage;
+    const int NKK = p.TG * p.KS;
+    const long long total = (long long)p.nchunk * p.NG * NKK * p.MFT * 64;  // (stage, kk, F, lane) items; each writes hi and lo 16 B
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
         int lane = (int)(it & 63);
         long long r = it >> 6;
-        int mf = (int)(r % MF);
-        r /= MF;
-        int kk = (int)(r % (p.TG * p.KS));
-        r /= (p.TG * p.KS);
+        int F = (int)(r % p.MFT);
+        r /= p.MFT;
+        int kk = (int)(r % NKK);
+        r /= NKK;
         int g = (int)(r % p.NG);
-        r /= p.NG;
-        int ch = (int)(r % p.nchunk);
-        int mt = (int)(r / p.nchunk);
+        int ch = (int)(r / p.NG);
         int tgi = kk / p.KS, ks = kk - tgi * p.KS;
         int t = g * p.TG + tgi;
-        int m = mt * p.BM + mf * 32 + (lane & 31);
+        int m = F * 32 + (lane & 31);
         int c0 = ch * 16 * p.KS + ks * 16 + 8 * (lane >> 5);
         float v[8];
 #pragma unroll
@@ -475,15 +503,13 @@ __global__ void conv_bf16x3_pack_kernel(CbPackParams p) {
             }
             v[e] = x;
         }
-        uint4 h, l;
-        cb_split2(v[0], v[1], h.x, l.x);
-        cb_split2(v[2], v[3], h.y, l.y);
-        cb_split2(v[4], v[5], h.z, l.z);
-        cb_split2(v[6], v[7], h.w, l.w);
-        long long stage = ((long long)mt * p.nchunk + ch) * p.NG + g;
-        char* base = p.dst + (stage * p.TG * p.KS * MF * 2 + ((long long)kk * MF + mf) * 2) * 1024 + lane * 16;
-        *reinterpret_cast<uint4*>(base) = h;
-        *reinterpret_cast<uint4*>(base + 1024) = l;
+        unsigned hh[4], ll[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cb_split2(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+        long long stage = (long long)ch * p.NG + g;
+        char* base = p.dst + (((stage * NKK + kk) * p.MFT + F) * 2) * 1024 + lane * 16;
+        *reinterpret_cast<u32x4*>(base) = u32x4{hh[0], hh[1], hh[2], hh[3]};
+        *reinterpret_cast<u32x4*>(base + 1024) = u32x4{ll[0], ll[1], ll[2], ll[3]};
     }
 }
 
@@ -493,24 +519,32 @@ __global__ void conv_bf16x3_pack_kernel(CbPackParams p) {
 namespace {
 
 struct CbPlan {
-    int BM, MT;
+    int mft;   // 32-row fragments = ceil(M / 32)
     int nseg;  // sub-convolutions (1, or 4 output-parity classes for ConvTranspose2d)
     int T[4], TG[4], KS[4];
     int ky[4][CB_MAX_TAPS], kx[4][CB_MAX_TAPS];  // weight tap
     int dy[4][CB_MAX_TAPS], dx[4][CB_MAX_TAPS];  // input offset of the tap
     int oy0[4], ox0[4];
     int nchunk[4];
-    long long mt_bytes[4], woff[4];
+    long long cls_bytes[4], woff[4];
     long long total_bytes;
 };
 
-// M-tile height.  192 when it divides the channel count with less per-CU work than 128 (M = 192: one tile instead of two
-// 25%-empty ones; M = 384: 2 x 192 halves the patch re-reads of 3 x 128); 7x7 kernels keep their 7-tap weight stages <= 64 rows.
-int cb_pick_bm(int M, int T, int stride) {
-    if (M <= 32 && stride == 1) return 32;   // (a 256-pixel stride-2 tile would not leave room for two patch buffers)
-    if (M <= 64 || T == 49) return 64;
-    if (M % 192 == 0 && M % 128 != 0) return 192;
-    return 128;
+// M-tile height, chosen per launch (the packed weights do not depend on it).  One workgroup per CU is resident, so the cost
+// of a launch is ~ rounds * (BM + fixed per-workgroup overhead): 192-row tiles win when they save a round or the 25 % padding
+// of a second 128-row tile (M = 192: 1 x 192 instead of 2 x 128; M = 384 at 256 pixel tiles: 2 rounds instead of 3).
+int cb_pick_bm(int M, int T, int stride, int batch, int GH, int GW) {
+    if (M <= 32) return 32;
+    if (M <= 64 || T == 49) return 64;       // 7x7 kernels keep their 7-tap weight stages small
+    const long long tiles = (long long)batch * lama_ceil_div64((long long)GH * GW, 128);
+    long long best = 0;
+    int bm = 128;
+    for (int cand : {128, 192}) {
+        long long rounds = lama_ceil_div64(tiles * lama_ceil_div(M, cand), 256);
+        long long cost = rounds * (cand + 24);
+        if (best == 0 || cost < best) { best = cost; bm = cand; }
+    }
+    return bm;
 }
 
 bool cb_stage_shape(int T, int* TG, int* KS) {
@@ -524,9 +558,8 @@ bool cb_stage_shape(int T, int* TG, int* KS) {
     return false;
 }
 
-bool cb_make_plan(int cout, int cin, int kh, int kw, int stride, int pad, int transposed, CbPlan* pl, int force_bm = 0) {
-    pl->BM = force_bm ? force_bm : cb_pick_bm(cout, transposed ? 4 : kh * kw, transposed ? 1 : stride);
-    pl->MT = lama_ceil_div(cout, pl->BM);
+bool cb_make_plan(int cout, int cin, int kh, int kw, int stride, int pad, int transposed, CbPlan* pl) {
+    pl->mft = lama_ceil_div(cout, 32);
     if (transposed) {
         if (kh != 3 || kw != 3 || stride != 2 || pad != 1) return false;
         pl->nseg = 4;
@@ -563,10 +596,9 @@ bool cb_make_plan(int cout, int cin, int kh, int kw, int stride, int pad, int tr
     for (int cls = 0; cls < pl->nseg; ++cls) {
         if (!cb_stage_shape(pl->T[cls], &pl->TG[cls], &pl->KS[cls])) return false;
         pl->nchunk[cls] = lama_ceil_div(cin, 16 * pl->KS[cls]);
-        long long stage = (long long)pl->TG[cls] * pl->KS[cls] * (pl->BM / 32) * 2048;
-        pl->mt_bytes[cls] = (long long)pl->nchunk[cls] * (pl->T[cls] / pl->TG[cls]) * stage;
+        pl->cls_bytes[cls] = (long long)pl->nchunk[cls] * pl->T[cls] * pl->KS[cls] * pl->mft * 2048;
         pl->woff[cls] = off;
-        off += pl->mt_bytes[cls] * pl->MT;
+        off += pl->cls_bytes[cls];
     }
     pl->total_bytes = off;
     return true;
@@ -582,7 +614,7 @@ int cb_fill_seg(CbSeg* s, const lama_tensor& x, const char* w, const CbPlan& pl,
     s->H = flat ? 1 : x.H;
     s->W = flat ? x.H * x.W : x.W;
     s->w = w;
-    s->mt_bytes = pl.mt_bytes[cls];
+    s->mft = pl.mft;
     s->nchunk = pl.nchunk[cls];
     s->NG = T / pl.TG[cls];
     s->stride = stride;
@@ -638,6 +670,14 @@ int cb_launch(hipStream_t st, const CbParams& p, int T1, int T2, int BM, int max
     if (shmem > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
     const int grid = p.B * p.tiles_x * p.tiles_y * p.MT;
     if (grid <= 0) return LAMA_OK;
+    if (T1 == 9 && T2 == 0 && BM == 128 && maxu <= 1) {   // profiling tools only: timing ablations of the bottleneck 3x3 kernel
+        const char* e = getenv("LAMA_CB_ABLATE");
+        const int abl = e ? atoi(e) : 0;
+#define CB_ABL(v) \
+    if (abl == v) { hipLaunchKernelGGL((conv_bf16x3_kernel<9, 3, 1, 0, 0, 0, 128, 1, v>), dim3(grid), dim3(CB_THREADS), shmem, st, p); LAMA_CHECK_LAUNCH(); return LAMA_OK; }
+        CB_ABL(1) CB_ABL(2) CB_ABL(4) CB_ABL(6) CB_ABL(7) CB_ABL(8) CB_ABL(14) CB_ABL(15)
+#undef CB_ABL
+    }
 #define CB_CASE(t1, g1, k1, t2, g2, k2) \
     if (T1 == t1 && T2 == t2) return cb_launch_bm<t1, g1, k1, t2, g2, k2>(st, p, BM, maxu, grid, shmem);
     CB_CASE(9, 3, 1, 0, 0, 0)
@@ -670,8 +710,7 @@ int lama_cb_pack_weight(hipStream_t stream, const float* w, const float* scale, 
         pp.dst = (char*)dst + pl.woff[cls];
         pp.M = cout;
         pp.C = cin;
-        pp.BM = pl.BM;
-        pp.MT = pl.MT;
+        pp.MFT = pl.mft;
         pp.TG = pl.TG[cls];
         pp.KS = pl.KS[cls];
         pp.NG = pl.T[cls] / pl.TG[cls];
@@ -680,7 +719,7 @@ int lama_cb_pack_weight(hipStream_t stream, const float* w, const float* scale, 
         pp.kw = kw;
         pp.transposed = transposed;
         for (int t = 0; t < pl.T[cls]; ++t) { pp.tap_ky[t] = pl.ky[cls][t]; pp.tap_kx[t] = pl.kx[cls][t]; }
-        long long total = pl.mt_bytes[cls] * pl.MT / 32;  // items of 2 x 16 B
+        long long total = pl.cls_bytes[cls] / 32;  // items of 2 x 16 B
         int grid = (int)((total + 255) / 256);
         if (grid > 4096) grid = 4096;
         hipLaunchKernelGGL(conv_bf16x3_pack_kernel, dim3(grid), dim3(256), 0, stream, pp);
@@ -696,8 +735,10 @@ int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, in
     if (!cb_make_plan(cout, cin, a->kh, a->kw, a->stride, a->pad, a->transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
     const bool has2 = a->x2.ptr != nullptr;
     CbPlan pl2;
-    if (has2 && (!cb_make_plan(cout, a->x2.C, 1, 1, 1, 0, 0, &pl2) || pl2.BM != pl.BM)) return LAMA_ERR_UNSUPPORTED;
-    const int BN = pl.BM >= 64 ? 128 : 256;
+    if (has2 && !cb_make_plan(cout, a->x2.C, 1, 1, 1, 0, 0, &pl2)) return LAMA_ERR_UNSUPPORTED;
+    int BM = cb_pick_bm(cout, pl.T[0], a->transposed ? 1 : a->stride, a->batch, a->transposed ? a->x.H : Ho, a->transposed ? a->x.W : Wo);
+    if (BM < 128 && !a->transposed && a->stride == 2) BM = 128;   // a 256-pixel stride-2 tile does not leave room for two patch buffers
+    const int BN = BM >= 128 ? 128 : 256;
     if ((long long)a->x.C * a->x.H * a->x.W >= (1ll << 31) || (has2 && (long long)a->x2.C * a->x2.H * a->x2.W >= (1ll << 31)))
         return LAMA_ERR_UNSUPPORTED;   // 32-bit element offsets inside one image
 
@@ -711,7 +752,7 @@ int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, in
         p.y = (float*)a->y.ptr;
         p.y_bstride = a->y.batch_stride;
         p.M = cout;
-        p.MT = pl.MT;
+        p.MT = lama_ceil_div(cout, BM);
         p.B = a->batch;
         p.act = a->act;
         if (flat) {
@@ -732,20 +773,20 @@ int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, in
         p.tiles_x = lama_ceil_div(p.GW, TW);
         p.tiles_y = lama_ceil_div(p.GH, TH);
         int units = cb_fill_seg(&p.s1, a->x, (const char*)a->w_packed + pl.woff[cls], pl, cls, stride, pad_mode, TH, TW, flat);
-        long long wbytes = (long long)pl.TG[cls] * pl.KS[cls] * (pl.BM / 32) * 2048;
+        long long wbytes = (long long)pl.TG[cls] * pl.KS[cls] * (BM / 32) * 2048;
         long long pbytes = (long long)2 * 2 * pl.KS[cls] * p.s1.npix * 16;
         int TG2 = 0, KS2 = 0;
         if (has2) {
             TG2 = pl2.TG[0]; KS2 = pl2.KS[0];
             int u2 = cb_fill_seg(&p.s2, a->x2, (const char*)a->w2_packed, pl2, 0, 1, LAMA_PAD_ZERO, TH, TW, false);
             units = u2 > units ? u2 : units;
-            long long w2 = (long long)TG2 * KS2 * (pl.BM / 32) * 2048, p2 = (long long)2 * 2 * KS2 * p.s2.npix * 16;
+            long long w2 = (long long)TG2 * KS2 * (BM / 32) * 2048, p2 = (long long)2 * 2 * KS2 * p.s2.npix * 16;
             wbytes = w2 > wbytes ? w2 : wbytes;
             pbytes = p2 > pbytes ? p2 : pbytes;
         }
         p.wbytes = (int)wbytes;
         p.pbytes = (int)pbytes;
-        int rc = cb_launch(stream, p, pl.T[cls], has2 ? 1 : 0, pl.BM, lama_ceil_div(units, CB_THREADS));
+        int rc = cb_launch(stream, p, pl.T[cls], has2 ? 1 : 0, BM, lama_ceil_div(units, CB_THREADS));
         if (rc != LAMA_OK) return rc;
     }
     return LAMA_OK;

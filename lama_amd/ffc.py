@@ -349,8 +349,12 @@ class FFC_BN_ACT(_HipModule):
 
     # -- launch --------------------------------------------------------------------------------------
     def run(self, src: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], resid: Optional[torch.Tensor] = None,
-            extra_pad: int = 0):
-        """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous)."""
+            extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None):
+        """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous).
+
+        ``side``: optional second HIP stream.  The spectral branch (conv1 -> rfft2 -> spectral 1x1 -> irfft2, HBM/latency
+        bound, small LDS footprint) then runs on it concurrently with the MFMA-bound local 3x3 conv of the main stream; the
+        two join before the global conv that consumes both.  Works inside hipGraph capture (fork/join via events)."""
         f, lib, prec = self.ffc, self._exec.lib, self.precision
         if f.in_cg and not (f.convg2g._packed or {}).get('fused_scale'):
             self._packed = None   # a stand-alone SpectralTransform.forward re-packed conv2 without bn_g
@@ -364,9 +368,17 @@ class FFC_BN_ACT(_HipModule):
             return
         cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
         spec = f.convg2g
-        spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st)
-        lib.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], self._act,
-                   None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+        if side is not None and src.is_cuda:
+            main = torch.cuda.current_stream(src.device)
+            side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream)
+            lib.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], self._act,
+                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+            main.wait_stream(side)                      # join: t is ready for the global conv
+        else:
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st)
+            lib.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], self._act,
+                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
         lib.conv2d(L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], self._act,
                    None if resid is None else L.view(resid, ocl, ocg), x2=L.view(scratch['t']), w2_packed=spec._packed['w2'],
                    precision=prec, stream=st)
@@ -414,9 +426,9 @@ class FFCResnetBlock(_HipModule):
                                 activation_layer=activation_layer, padding_type=padding_type, **conv_kwargs)
         self.inline = inline
 
-    def run(self, src: torch.Tensor, tmp: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict]):
-        self.conv1.run(src, tmp, scratch)
-        self.conv2.run(tmp, dst, scratch, resid=src)
+    def run(self, src: torch.Tensor, tmp: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], side=None):
+        self.conv1.run(src, tmp, scratch, side=side)
+        self.conv2.run(tmp, dst, scratch, resid=src, side=side)
 
     def forward(self, x):
         x_l, x_g = x if type(x) is tuple else (x, 0)
@@ -629,6 +641,7 @@ class FFCResNetGenerator(_HipModule):
             model.append(Activation(kind))
         self.model = LayerSequence(*model)
         self.use_graph = False
+        self.overlap_streams = True    # spectral branch on a second stream next to the local 3x3 conv (fused forward only)
         self._plans = {}
         super().train(False)
 
@@ -695,7 +708,8 @@ class FFCResNetGenerator(_HipModule):
             else:
                 raise LamaError(f'no fused plan for layer {type(lay).__name__}; run generator.model layer by layer')
             i += 1
-        return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None)
+        side = torch.cuda.Stream(device=device) if (self.overlap_streams and torch.device(device).type == 'cuda') else None
+        return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None, side=side)
 
     def _run_plan(self, plan, x):
         bufs = plan['bufs']
@@ -707,10 +721,10 @@ class FFCResNetGenerator(_HipModule):
             kind = st[0]
             if kind == 'ffc':
                 _, lay, s, d, pad = st
-                lay.run(B(s), B(d), plan['scratch'] if lay.ffc.in_cg else None, None, pad)
+                lay.run(B(s), B(d), plan['scratch'] if lay.ffc.in_cg else None, None, pad, side=plan['side'])
             elif kind == 'res':
                 _, lay, s, t, d = st
-                lay.run(B(s), B(t), B(d), plan['scratch'])
+                lay.run(B(s), B(t), B(d), plan['scratch'], side=plan['side'])
             elif kind == 'up':
                 _, lay, s, d, bn, act = st
                 lay.run(B(s), B(d), bn, act)

@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Run selected bottleneck kernels a few times (for rocprofv3 --pmc passes).  usage: kprobe.py [bf16x3|f32] [names...]
+names: convA convB conv1 fuconv rfft irfft down1 up3 stem head"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lama_amd import _lib as L  # noqa: E402
+
+
+def main():
+    prec = L.PREC_F32 if (len(sys.argv) > 1 and sys.argv[1] == 'f32') else L.PREC_BF16X3
+    names = sys.argv[2:] or ['convA', 'convB', 'conv1', 'fuconv', 'rfft', 'irfft']
+    iters = int(os.environ.get('KPROBE_ITERS', '10'))
+    lib = L.get_lib()
+    dev = 'cuda'
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(0)
+    B, h, w = 8, 64, 64
+
+    def rnd(*s):
+        return torch.randn(*s, generator=g).to(dev)
+
+    def conv(cin, cout, k, H, W, stride=1, tr=False, x2c=0):
+        x = rnd(B, cin, H, W)
+        wt = rnd(cin, cout, k, k) if tr else rnd(cout, cin, k, k)
+        s2 = 2 if tr else stride
+        wp = lib.pack_conv_weight(wt, None, stride=s2, transposed=tr, precision=prec)
+        Ho, Wo = (2 * H, 2 * W) if tr else ((H + 2 * (k // 2) - k) // s2 + 1, (W + 2 * (k // 2) - k) // s2 + 1)
+        y = torch.empty(B, cout, Ho, Wo, device=dev)
+        bias = rnd(cout)
+        x2 = w2p = None
+        if x2c:
+            x2 = rnd(B, x2c, Ho, Wo)
+            w2p = lib.pack_conv_weight(rnd(cout, x2c, 1, 1), None, precision=prec)
+        return lambda: lib.conv2d(L.view(x), wp, L.view(y), B, k, s2, 1 if tr else k // 2, L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
+                                  L.ACT_RELU, None, None if x2 is None else L.view(x2), w2p, precision=prec, stream=st)
+
+    x1 = rnd(B, 192, h, w)
+    spec = torch.empty(B, 384, h, w // 2 + 1, device=dev)
+    y = torch.empty_like(x1)
+    table = {
+        'convA': lambda: conv(512, 128, 3, h, w),
+        'convB': lambda: conv(128, 384, 3, h, w, x2c=192),
+        'conv1': lambda: conv(384, 192, 1, h, w),
+        'fuconv': lambda: conv(384, 384, 1, h, 33),
+        'down1': lambda: conv(64, 128, 3, 512, 512, stride=2),
+        'down3': lambda: conv(256, 512, 3, 128, 128, stride=2),
+        'up3': lambda: conv(128, 64, 3, 256, 256, tr=True),
+        'stem': lambda: conv(4, 64, 7, 512, 512),
+        'head': lambda: conv(64, 3, 7, 512, 512),
+        'rfft': lambda: (lambda: lib.rfft2(L.view(x1), L.view(spec), B, None, st)),
+        'irfft': lambda: (lambda: lib.irfft2(L.view(spec), L.view(x1), L.view(y), B, None, st)),
+    }
+    for n in names:
+        fn = table[n]()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        print(n, round(a.elapsed_time(b) * 1e3 / iters, 2), 'us', flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Average rocprofv3 counter_collection.csv per (kernel, counter).  usage: pmc_summary.py file.csv"""
+import collections
+import csv
+import sys
+
+acc = collections.defaultdict(lambda: [0.0, 0])
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r.get('Kernel_Name', '')[:70]
+    c = r.get('Counter_Name')
+    v = float(r.get('Counter_Value', 0))
+    a = acc[(k, c)]
+    a[0] += v
+    a[1] += 1
+for (k, c), (s, n) in sorted(acc.items()):
+    print(f'{k:70s} {c:28s} avg={s / n:16.1f} n={n}')
