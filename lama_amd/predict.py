@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Batched, data-parallel mirror of ``bin/predict.py`` (reference lines 38-100) on the HIP path.
+
+    python -m lama_amd.predict model.path=<dir> indir=<dir> outdir=<dir> \
+        [model.checkpoint=best.ckpt] [dataset.img_suffix=.png] [dataset.pad_out_to_modulo=8] [out_ext=.png] \
+        [batch_size=8] [precision=bf16x3|f32]
+    python -m torch.distributed.run --nproc-per-node N -m lama_amd.predict ...        # one process per GPU
+
+Same on-disk contract as the reference: masks are ``**/*mask*.png`` (sorted, recursive), the image of a mask
+is ``<mask path up to '_mask'><img_suffix>`` (``evaluation/data.py:59-62``), the result of a mask is written to
+``<outdir>/<mask path relative to indir, extension replaced by out_ext>`` (``bin/predict.py:69-72``) as
+``clip(inpainted*255, 0, 255).astype(uint8)`` cropped to the unpadded size (``bin/predict.py:86-94``).
+
+What differs from the reference's batch-1 Python loop: images are padded to ``pad_out_to_modulo`` and *bucketed by
+padded shape*, each bucket is cut into batches, batches are dealt round-robin to the ranks (one process per GPU,
+weights replicated, no communication during compute), the u8 HWC results are produced on the device and the only
+collective is one all-gather of those output images per round (RCCL over xGMI on GPUs, gloo in the CPU tests); rank 0
+writes the PNGs on a thread pool so file IO overlaps the next round's compute.
+"""
+from __future__ import annotations
+
+import glob
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import config as lcfg
+from . import trainers
+
+DEFAULTS = {'model.checkpoint': 'best.ckpt', 'dataset.img_suffix': '.png', 'dataset.pad_out_to_modulo': 8,
+            'out_ext': '.png', 'out_key': 'inpainted', 'batch_size': 8, 'precision': 'bf16x3'}   # configs/prediction/default.yaml
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# dataset glue (saicinpainting/evaluation/data.py:12-33,58-83)
+# ----------------------------------------------------------------------------------------------------------------
+
+def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
+    """Hydra-style ``a.b=c`` overrides on top of configs/prediction/default.yaml's defaults."""
+    cfg = dict(DEFAULTS)
+    for a in argv:
+        if '=' not in a:
+            raise SystemExit(f'expected key=value, got {a!r}')
+        k, v = a.split('=', 1)
+        cfg[k] = int(v) if v.lstrip('-').isdigit() else v
+    for need in ('model.path', 'indir', 'outdir'):
+        if need not in cfg:
+            raise SystemExit(f'missing {need}=...')
+    return cfg
+
+
+def list_dataset(indir: str, img_suffix: str = '.png') -> List[Tuple[str, str]]:
+    """(mask path, image path) pairs: InpaintingDataset.__init__, evaluation/data.py:59-62."""
+    masks = sorted(glob.glob(os.path.join(indir, '**', '*mask*.png'), recursive=True))
+    return [(m, m.rsplit('_mask', 1)[0] + img_suffix) for m in masks]
+
+
+def load_image(fname: str, mode: str = 'RGB') -> np.ndarray:
+    """evaluation/data.py:12-20 (PIL instead of cv2: same decoded values)."""
+    from PIL import Image
+    img = np.array(Image.open(fname).convert(mode))
+    if img.ndim == 3:
+        img = np.transpose(img, (2, 0, 1))
+    return img.astype('float32') / 255
+
+
+def ceil_modulo(x: int, mod: int) -> int:
+    return x if x % mod == 0 else (x // mod + 1) * mod
+
+
+def pad_img_to_modulo(img: np.ndarray, mod: int) -> np.ndarray:
+    """evaluation/data.py:29-33: symmetric padding at the bottom / right."""
+    c, h, w = img.shape
+    return np.pad(img, ((0, 0), (0, ceil_modulo(h, mod) - h), (0, ceil_modulo(w, mod) - w)), mode='symmetric')
+
+
+def load_item(mask_path: str, img_path: str, pad_mod: int):
+    """InpaintingDataset.__getitem__, evaluation/data.py:69-83 -> (image [3,H',W'], mask [1,H',W'], (H, W))."""
+    image = load_image(img_path, 'RGB')
+    mask = load_image(mask_path, 'L')[None, ...]
+    hw = image.shape[1:]
+    if pad_mod and pad_mod > 1:
+        image, mask = pad_img_to_modulo(image, pad_mod), pad_img_to_modulo(mask, pad_mod)
+    return image, mask, hw
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# work distribution
+# ----------------------------------------------------------------------------------------------------------------
+
+def plan_rounds(shapes: Sequence[Tuple[int, int]], batch_size: int, world: int) -> List[dict]:
+    """Bucket item indices by padded shape, cut buckets into batches, deal the batches of a bucket round-robin to ranks.
+    Returns rounds: dict(shape=(H', W'), batches=[item-index list per rank (possibly empty)])."""
+    buckets: Dict[Tuple[int, int], List[int]] = {}
+    for i, s in enumerate(shapes):
+        buckets.setdefault(tuple(s), []).append(i)
+    rounds = []
+    for shape in sorted(buckets):
+        idx = buckets[shape]
+        batches = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
+        for r0 in range(0, len(batches), world):
+            chunk = batches[r0:r0 + world]
+            rounds.append(dict(shape=shape, batches=chunk + [[] for _ in range(world - len(chunk))]))
+    return rounds
+
+
+def _write_png(path: str, rgb: np.ndarray):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(rgb).save(path)         # the reference converts RGB->BGR only because cv2.imwrite expects BGR
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the predict loop
+# ----------------------------------------------------------------------------------------------------------------
+
+def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[str, str]], indir: str, outdir: str, *,
+            pad_mod: int = 8, batch_size: int = 8, out_ext: str = '.png', device='cuda', rank: int = 0, world: int = 1,
+            dist=None, io_threads: int = 8) -> int:
+    """Run every (mask, image) pair through ``model`` and write the results (rank 0).  Returns the number of images written."""
+    from PIL import Image
+    shapes = []
+    for m, _ in items:                       # padded shape from the PNG header only: every rank builds the same plan
+        with Image.open(m) as im:
+            w, h = im.size
+        shapes.append((ceil_modulo(h, pad_mod), ceil_modulo(w, pad_mod)) if pad_mod and pad_mod > 1 else (h, w))
+    rounds = plan_rounds(shapes, batch_size, world)
+    lib = model.generator._exec.lib
+    pool = ThreadPoolExecutor(io_threads) if rank == 0 else None
+    futures, written = [], 0
+    for rd in rounds:
+        Hp, Wp = rd['shape']
+        mine = rd['batches'][rank]
+        u8 = torch.zeros(batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
+        if mine:
+            loaded = [load_item(*items[i], pad_mod) for i in mine]
+            image = torch.from_numpy(np.stack([x[0] for x in loaded])).to(device)
+            mask = torch.from_numpy(np.stack([x[1] for x in loaded])).to(device)
+            batch = dict(image=image, mask=(mask > 0) * 1)                          # bin/predict.py:84
+            with torch.no_grad():
+                out = model(batch)['inpainted']                                    # bin/predict.py:85, out_key
+            stream = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else 0
+            lib.quantize_u8_hwc(L.view(out), u8, len(mine), Hp, Wp, stream)        # bin/predict.py:92 on the device
+        if world > 1:
+            gathered = torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
+            dist.all_gather_into_tensor(gathered, u8)                              # the only collective: output images
+        else:
+            gathered = u8
+        if rank == 0:
+            host = gathered.cpu().numpy()
+            for r, idxs in enumerate(rd['batches']):
+                for j, i in enumerate(idxs):
+                    mask_path = items[i][0]
+                    with Image.open(mask_path) as im:
+                        w, h = im.size
+                    rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + out_ext      # bin/predict.py:69-72
+                    futures.append(pool.submit(_write_png, os.path.join(outdir, rel), host[r * batch_size + j, :h, :w].copy()))
+                    written += 1
+    for f in futures:
+        f.result()
+    if pool:
+        pool.shutdown()
+    return written
+
+
+def main(argv: Optional[Sequence[str]] = None) -> int:
+    cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise L.LamaError('lama_amd.predict needs an MI355X: no GPU is visible (there is no CPU fallback)')
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)
+    train_config = lcfg.load_train_config(os.path.join(cfg['model.path'], 'config.yaml'))           # bin/predict.py:46-48
+    ckpt = os.path.join(cfg['model.path'], 'models', cfg['model.checkpoint'])                       # bin/predict.py:55-57
+    model = trainers.load_checkpoint(train_config, ckpt, strict=False, map_location=device)         # bin/predict.py:58
+    model.freeze()
+    model.generator.set_precision(L.PREC_F32 if cfg['precision'] == 'f32' else L.PREC_BF16X3)
+    model.generator.use_graph = True
+    indir = cfg['indir'] if cfg['indir'].endswith(os.sep) else cfg['indir'] + os.sep               # bin/predict.py:63-64
+    items = list_dataset(indir, cfg['dataset.img_suffix'])
+    n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
+                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist)
+    if rank == 0:
+        print(f'wrote {n} images to {cfg["outdir"]}')
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
