@@ -151,7 +151,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--precision', default=os.environ.get('LAMA_PRECISION', 'bf16x3'), choices=['f32', 'bf16x3'])
+    ap.add_argument('--precision', default=os.environ.get('LAMA_PRECISION', 'f16x3'), choices=['f32', 'bf16x3', 'f16x3'])
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-fp32 timing leg')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -171,7 +171,7 @@ def main():
             raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    precision = L.PREC_F32 if args.precision == 'f32' else L.PREC_BF16X3
+    precision = L.PREC_NAMES[args.precision]
 
     lib = L.get_lib()                      # raises if the HIP library is missing: no fallback
     timer = KernelTimer(lib)
@@ -230,7 +230,7 @@ def main():
                         traffic=pmc_traffic(dom, args.precision), avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
-                             'fp32 accuracy via 3-term bf16 split on v_mfma_f32_32x32x16_bf16: peak = 2500 TF dense bf16 / 3 MFMA products per '
+                             f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
                              'algorithmic product; achieved counts algorithmic FLOPs only')
         fu = next((k for k in kern if k.startswith('fourier_unit')), None)
         if fu:
@@ -269,7 +269,7 @@ def main():
             'metric': 'inpainted images/sec at 512x512 big-lama',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32' if precision == L.PREC_F32 else 'f32 (3-term bf16-split MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',
+            'dtype': 'f32' if precision == L.PREC_F32 else f'f32 (3-term {args.precision[:-2]} split on the 16-bit MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',
             'config': {'workload': f'big-lama FFCResNetGenerator 512x512 batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
                                    f'mask-compose + generator + blend + u8, random-init weights',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',

@@ -43,7 +43,8 @@ extern "C" {
 
 /* arithmetic of the MFMA contraction */
 #define LAMA_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain)          */
-#define LAMA_PREC_BF16X3 1 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_bf16 */
+#define LAMA_PREC_BF16X3 1 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_bf16: fp32 range  */
+#define LAMA_PREC_F16X3 2  /* 3-term fp16 split on v_mfma_f32_32x32x16_f16: 22 mantissa bits, |x| <= 65504     */
 
 typedef struct lama_tensor {
     void* ptr;            /* device pointer to element (0,0,0,0) of the view; NULL = absent          */

@@ -14,7 +14,8 @@ import torch
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
-PREC_F32, PREC_BF16X3 = 0, 1
+PREC_F32, PREC_BF16X3, PREC_F16X3 = 0, 1, 2
+PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
 

@@ -45,8 +45,13 @@ __device__ __forceinline__ int lama_xcd_remap(int orig, int nwg) {
 #define LAMA_KEEP_LIVE(x) asm volatile("" ::"v"(x))
 #endif
 
-// bf16x3 convolution back end (conv_bf16x3.hip), reached through lama_conv2d_* with LAMA_PREC_BF16X3
-int64_t lama_cb_packed_weight_bytes(int cout, int cin, int kh, int kw, int stride, int transposed);
-int lama_cb_pack_weight(hipStream_t stream, const float* w, const float* scale, int cout, int cin, int kh, int kw, int stride,
-                        int transposed, void* dst);
-int lama_cb_conv2d_fwd(hipStream_t stream, const lama_conv2d_args* a, int Ho, int Wo);
+// 3-term split convolution back ends (conv_split3.inc compiled as conv_bf16x3.hip / conv_f16x3.hip), reached through
+// lama_conv2d_* with LAMA_PREC_BF16X3 / LAMA_PREC_F16X3
+#define LAMA_CB_DECL(sfx)                                                                                                        \
+    int64_t lama_cb_packed_weight_bytes##sfx(int cout, int cin, int kh, int kw, int stride, int transposed);                       \
+    int lama_cb_pack_weight##sfx(hipStream_t stream, const float* w, const float* scale, int cout, int cin, int kh, int kw,       \
+                                 int stride, int transposed, void* dst);                                                         \
+    int lama_cb_conv2d_fwd##sfx(hipStream_t stream, const lama_conv2d_args* a, int Ho, int Wo);
+LAMA_CB_DECL(_bf16x3)
+LAMA_CB_DECL(_f16x3)
+#undef LAMA_CB_DECL

@@ -115,7 +115,7 @@ _DEFAULT_EXEC = _Exec()
 class _HipModule(nn.Module):
     """Base: packed-weight cache that is dropped whenever parameters may have changed."""
 
-    precision = L.PREC_F32
+    precision = L.PREC_F16X3     # fp32-accurate 3-term fp16 split on the 16-bit MFMA; PREC_F32 = exact fmaf-chain MFMA (5x slower)
 
     def __init__(self):
         super().__init__()

@@ -3,7 +3,7 @@
 
     python -m lama_amd.predict model.path=<dir> indir=<dir> outdir=<dir> \
         [model.checkpoint=best.ckpt] [dataset.img_suffix=.png] [dataset.pad_out_to_modulo=8] [out_ext=.png] \
-        [batch_size=8] [precision=bf16x3|f32]
+        [batch_size=8] [precision=f16x3|bf16x3|f32]
     python -m torch.distributed.run --nproc-per-node N -m lama_amd.predict ...        # one process per GPU
 
 Same on-disk contract as the reference: masks are ``**/*mask*.png`` (sorted, recursive), the image of a mask
@@ -33,7 +33,7 @@ from . import config as lcfg
 from . import trainers
 
 DEFAULTS = {'model.checkpoint': 'best.ckpt', 'dataset.img_suffix': '.png', 'dataset.pad_out_to_modulo': 8,
-            'out_ext': '.png', 'out_key': 'inpainted', 'batch_size': 8, 'precision': 'bf16x3'}   # configs/prediction/default.yaml
+            'out_ext': '.png', 'out_key': 'inpainted', 'batch_size': 8, 'precision': 'f16x3'}   # configs/prediction/default.yaml
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -186,7 +186,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     ckpt = os.path.join(cfg['model.path'], 'models', cfg['model.checkpoint'])                       # bin/predict.py:55-57
     model = trainers.load_checkpoint(train_config, ckpt, strict=False, map_location=device)         # bin/predict.py:58
     model.freeze()
-    model.generator.set_precision(L.PREC_F32 if cfg['precision'] == 'f32' else L.PREC_BF16X3)
+    model.generator.set_precision(L.PREC_NAMES[cfg['precision']])
     model.generator.use_graph = True
     indir = cfg['indir'] if cfg['indir'].endswith(os.sep) else cfg['indir'] + os.sep               # bin/predict.py:63-64
     items = list_dataset(indir, cfg['dataset.img_suffix'])

@@ -210,6 +210,28 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_bf16(V8 a, V8 b, hipemu_f32
     }
     return c;
 }
+// 32x32x16 f16: same fragment map as bf16
+template <class V8>
+static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(V8 a, V8 b, hipemu_f32x16 c) {
+    uint32_t mine[8];
+    memcpy(&mine[0], &a, 16);
+    memcpy(&mine[4], &b, 16);
+    auto all = hipemu::exchange(mine, 8);
+    int l = hipemu::lane();
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double acc = 0.0;
+        for (int kg = 0; kg < 2; ++kg) {
+            const _Float16* ap = reinterpret_cast<const _Float16*>(&all[row + 32 * kg][0]);
+            const _Float16* bp = reinterpret_cast<const _Float16*>(&all[col + 32 * kg][4]);
+            for (int e = 0; e < 8; ++e) acc += (double)(float)ap[e] * (double)(float)bp[e];
+        }
+        c[r] = (float)((double)c[r] + acc);
+    }
+    return c;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_f32_32x32x16_f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_f32_32x32x2f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32_16x16x4f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma_f32_32x32x16_bf16(a, b, c)

@@ -46,12 +46,13 @@ CONV_CASES = [
 ]
 
 
-PRECISIONS = [L.PREC_F32, L.PREC_BF16X3]
-# max-abs tolerance: the exact-fp32 MFMA path is an fmaf chain; the 3-term bf16 split drops wl*xl (2^-16 relative per product)
-CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-4, rtol=2e-4)}
+PRECISIONS = [L.PREC_F32, L.PREC_BF16X3, L.PREC_F16X3]
+PREC_IDS = ['f32', 'bf16x3', 'f16x3']
+# max-abs tolerance: the exact-fp32 MFMA path is an fmaf chain; the 3-term splits carry 16 (bf16) / 22 (f16) mantissa bits
+CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-4, rtol=2e-4), L.PREC_F16X3: dict(atol=2e-4, rtol=1e-4)}
 
 
-@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
 def test_conv2d_emulated(case, prec):
     lib = emu_lib()
@@ -75,7 +76,7 @@ def test_conv2d_emulated(case, prec):
     assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0   # nothing written outside the view
 
 
-@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 def test_conv2d_fused_second_operand_emulated(prec):
     """out_g = relu(convl2g(x_l) + conv2(t) + b) + resid in one launch (ffc.py:161,223,253-254,288)."""
     lib = emu_lib()

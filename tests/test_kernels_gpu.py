@@ -10,7 +10,7 @@ from lama_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-from tests.test_kernels_emu import CONV_CASES, CONV_TOL, FFT_SIZES, PRECISIONS, _conv_ref, _inv_ref, _spec_ref  # noqa: E402
+from tests.test_kernels_emu import CONV_CASES, CONV_TOL, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_ref, _inv_ref, _spec_ref  # noqa: E402
 
 
 @pytest.fixture(scope='module')
@@ -22,7 +22,7 @@ def lib():
 DEV = 'cuda'
 
 
-@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
 def test_conv2d(lib, case, prec):
     g = torch.Generator().manual_seed(1)
@@ -49,7 +49,7 @@ def test_conv2d(lib, case, prec):
     assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0
 
 
-@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 @pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
                                    (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64)])
 def test_conv2d_big_tiles(lib, shape, prec):
@@ -69,7 +69,7 @@ def test_conv2d_big_tiles(lib, shape, prec):
     assert torch.allclose(y.cpu(), ref, atol=3e-4, rtol=1e-4), float((y.cpu() - ref).abs().max())
 
 
-@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 def test_conv2d_fused_second_operand_full_size(lib, prec):
     """The bottleneck global-branch launch at full channel counts: relu(conv3x3(x_l) + conv1x1(t) + b) + resid."""
     g = torch.Generator().manual_seed(12)
@@ -114,7 +114,7 @@ def test_rfft2_irfft2(lib, hw):
     assert torch.allclose(y.cpu(), ref2, atol=tol, rtol=1e-4), float((y.cpu() - ref2).abs().max())
 
 
-@pytest.mark.parametrize('prec', PRECISIONS, ids=['f32', 'bf16x3'])
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 def test_fourier_unit_c2_shape(lib, prec):
     """FourierUnit at the BASELINE config-2 shape [8,192,64,64] against the oracle."""
     from oracle import lama_oracle as O

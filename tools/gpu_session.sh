@@ -7,8 +7,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== kernel tests" | tee $OUT/summary.txt
 timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q 2>&1 | tail -15 | tee -a $OUT/summary.txt
-echo "== kbench bf16x3" | tee -a $OUT/summary.txt
-timeout 300 python tools/kbench.py bf16x3 > $OUT/kbench_bf16x3.log 2>&1; tail -3 $OUT/kbench_bf16x3.log | tee -a $OUT/summary.txt
+echo "== kbench f16x3" | tee -a $OUT/summary.txt
+timeout 300 python tools/kbench.py f16x3 > $OUT/kbench_f16x3.log 2>&1; tail -3 $OUT/kbench_f16x3.log | tee -a $OUT/summary.txt
 echo "== bench" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --steps 20 --warmup 3 > $OUT/bench.log 2>&1; tail -2 $OUT/bench.log | tee -a $OUT/summary.txt
 if [ "$2" != "quick" ]; then

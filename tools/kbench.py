@@ -27,8 +27,8 @@ def timeit(fn, iters=20, warm=3):
 
 
 def main():
-    prec = L.PREC_BF16X3 if (len(sys.argv) > 1 and sys.argv[1] == 'bf16x3') else L.PREC_F32
-    tag = 'bf16x3' if prec == L.PREC_BF16X3 else 'f32'
+    tag = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
+    prec = L.PREC_NAMES[tag]
     lib = L.get_lib()
     dev = 'cuda'
     st = torch.cuda.current_stream().cuda_stream

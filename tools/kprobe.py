@@ -12,7 +12,7 @@ from lama_amd import _lib as L  # noqa: E402
 
 
 def main():
-    prec = L.PREC_F32 if (len(sys.argv) > 1 and sys.argv[1] == 'f32') else L.PREC_BF16X3
+    prec = L.PREC_NAMES[sys.argv[1] if len(sys.argv) > 1 else 'f16x3']
     names = sys.argv[2:] or ['convA', 'convB', 'conv1', 'fuconv', 'rfft', 'irfft']
     iters = int(os.environ.get('KPROBE_ITERS', '10'))
     lib = L.get_lib()
