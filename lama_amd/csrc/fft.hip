@@ -159,17 +159,21 @@ __device__ __forceinline__ void rowpair_item(int item, int wq, int& f, int& q) {
     f = f_hi * 4 + f_lo;
 }
 
+// HT / WT: compile-time plane size (0 = take it from the parameters).  With constant sizes every div / mod of the item
+// decomposition folds to shifts and the pass loops unroll -- the generic instantiation is VALU-bound on that index math.
+template <int HT, int WT, int PPW>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
-    const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
+    const int h = HT ? HT : p.h, w = WT ? WT : p.w, wf = w / 2 + 1, hh = h >> 1, wh = w >> 1;
     const int RSW = w + 1;
-    const int bufsz = p.ppw * (hh * RSW > h * wf ? hh * RSW : h * wf);
+    const int bufsz = (PPW ? PPW : p.ppw) * (hh * RSW > h * wf ? hh * RSW : h * wf);
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* twh = tww + w;
     float2* P = twh + h;
     float2* Q = P + bufsz;
     const int tid = threadIdx.x;
-    const int plane0 = blockIdx.x * p.ppw;
-    const int np = (p.nplanes - plane0) < p.ppw ? (p.nplanes - plane0) : p.ppw;
+    const int ppw = PPW ? PPW : p.ppw;   // the sized instantiations are only launched when ppw divides the plane count
+    const int plane0 = blockIdx.x * ppw;
+    const int np = PPW ? PPW : ((p.nplanes - plane0) < ppw ? (p.nplanes - plane0) : ppw);
 
     fft_init_twiddles<false>(tww, w);
     fft_init_twiddles<false>(twh, h);
@@ -249,17 +253,19 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
     }
 }
 
+template <int HT, int WT, int PPW>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) {
-    const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
+    const int h = HT ? HT : p.h, w = WT ? WT : p.w, wf = w / 2 + 1, hh = h >> 1, wh = w >> 1;
     const int RSW = w + 1;
-    const int bufsz = p.ppw * (hh * RSW > h * wf ? hh * RSW : h * wf);
+    const int bufsz = (PPW ? PPW : p.ppw) * (hh * RSW > h * wf ? hh * RSW : h * wf);
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* twh = tww + w;
     float2* P = twh + h;
     float2* Q = P + bufsz;
     const int tid = threadIdx.x;
-    const int plane0 = blockIdx.x * p.ppw;
-    const int np = (p.nplanes - plane0) < p.ppw ? (p.nplanes - plane0) : p.ppw;
+    const int ppw = PPW ? PPW : p.ppw;   // the sized instantiations are only launched when ppw divides the plane count
+    const int plane0 = blockIdx.x * ppw;
+    const int np = PPW ? PPW : ((p.nplanes - plane0) < ppw ? (p.nplanes - plane0) : ppw);
     const int per_plane = h * wf;
 
     fft_init_twiddles<true>(tww, w);
@@ -523,7 +529,12 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     if (fft_fast_ok(p.h, p.w) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4)) & 15) == 0) {
         p.ppw = fft_ppw(p.h, p.w);
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
-        hipLaunchKernelGGL(rfft2_lds_kernel, dim3(lama_ceil_div(p.nplanes, p.ppw)), dim3(LAMA_NTHREADS), lds, st, p);
+        const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
+        const bool even = p.nplanes % p.ppw == 0;
+        if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
+        else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((rfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
+        else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
+        else hipLaunchKernelGGL((rfft2_lds_kernel<0, 0, 0>), grid, blk, lds, st, p);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
@@ -564,7 +575,12 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     if (fft_fast_ok(p.h, p.w) && (al & 15) == 0) {
         p.ppw = fft_ppw(p.h, p.w);
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
-        hipLaunchKernelGGL(irfft2_lds_kernel, dim3(lama_ceil_div(p.nplanes, p.ppw)), dim3(LAMA_NTHREADS), lds, st, p);
+        const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
+        const bool even = p.nplanes % p.ppw == 0;
+        if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
+        else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((irfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
+        else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
+        else hipLaunchKernelGGL((irfft2_lds_kernel<0, 0, 0>), grid, blk, lds, st, p);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
