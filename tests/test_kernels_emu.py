@@ -43,6 +43,7 @@ CONV_CASES = [
     dict(cin=140, cout=130, k=3, stride=1, pad=1, H=8, W=8, act=1, bias=True, resid=True, scale=True),
     dict(cin=24, cout=192, k=1, stride=1, pad=0, H=9, W=16, act=1, bias=True, resid=False, scale=True),     # 192-row M tiles (bf16x3)
     dict(cin=20, cout=384, k=3, stride=1, pad=1, H=6, W=36, act=1, bias=True, resid=True, scale=False),
+    dict(cin=24, cout=70, k=3, stride=2, pad=1, H=9, W=34, act=1, bias=True, resid=False, scale=True, transposed=True),   # fused classes, BM=128
 ]
 
 

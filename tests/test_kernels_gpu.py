@@ -70,6 +70,26 @@ def test_conv2d_big_tiles(lib, shape, prec):
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
+@pytest.mark.parametrize('shape', [(2, 128, 64, 40, 72), (1, 256, 130, 24, 40), (2, 512, 256, 16, 16)], ids=lambda s: f'c{s[1]}o{s[2]}')
+def test_conv_transpose_full_size(lib, shape, prec):
+    """ConvTranspose2d(k3, s2, p1, op1) + folded BN + ReLU at the upsampling layers' channel counts (ffc.py:348-354): the split
+    paths run it as ONE launch with four accumulator sets, the exact-fp32 path as four parity-class launches."""
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cin, cout, 3, 3, generator=g) / (cin * 2.25) ** 0.5
+    scale, bias = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    ref = _conv_ref(x, w, 2, 1, False, True, bias, 1, None, scale=scale)
+    wp = lib.pack_conv_weight(w.to(DEV), scale.to(DEV), stride=2, transposed=True, precision=prec)
+    y = torch.full((B, cout, 2 * H, 2 * W), 7.0, device=DEV)
+    xd, bd = x.to(DEV), bias.to(DEV)
+    lib.conv2d(L.view(xd), wp, L.view(y), B, 3, 2, 1, L.PAD_ZERO, True, bd, L.ACT_RELU, precision=prec, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    err = float((y.cpu() - ref).abs().max())
+    assert err < 3e-4, err
+
+
+@pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 def test_conv2d_fused_second_operand_full_size(lib, prec):
     """The bottleneck global-branch launch at full channel counts: relu(conv3x3(x_l) + conv1x1(t) + b) + resid."""
     g = torch.Generator().manual_seed(12)
