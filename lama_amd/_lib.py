@@ -53,7 +53,7 @@ def view(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Ten
 
 class LamaLib:
     def __init__(self, path: Optional[str] = None):
-        path = path or _DEFAULT
+        path = path or os.environ.get('LAMA_HIP_LIB') or _DEFAULT     # LAMA_HIP_LIB: A/B-testing another build of the same ABI
         if not os.path.exists(path):
             raise LamaError(f'{path} not found: build it with `python -m lama_amd.build` '
                             f'(hipcc --offload-arch=gfx950); lama_amd has no fallback path')
