@@ -122,7 +122,7 @@ def pmc_traffic(kernel_key, precision):
             continue
         e = d.get(precision, {}).get(kernel_key)
         if e:
-            return e
+            return dict(e, source=os.path.relpath(f, ROOT))
     return None
 
 
@@ -227,7 +227,8 @@ def main():
         if flops:
             ach = flops / kern[dom]['avg_us'] / 1e6
             roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
-                        traffic=pmc_traffic(dom, args.precision), avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
+                        traffic=(pmc_traffic(dom, args.precision) or {}).get('traffic_bytes'), traffic_detail=pmc_traffic(dom, args.precision),
+                        avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
@@ -236,8 +237,10 @@ def main():
         if fu:
             alg = 2 * BATCH * 192 * h * h * 4 + 384 * 384 * 4 + 384 * 4       # read x, write y, weights once
             gbs = alg / kern[fu]['avg_us'] / 1e3
+            parts = [pmc_traffic(k, args.precision) for k in ('rfft2_192x64x64', 'conv1x1_cin384_cout384_64x33', 'irfft2_192x64x64')]
+            ffc_traffic = sum(p_['traffic_bytes'] for p_ in parts) if all(parts) else None
             roof_ffc = dict(unit_of_work='FourierUnit forward [8,192,64,64] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
-                            peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                            peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=ffc_traffic,
                             avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg)
 
     # extra leg (rank 0, N = 1): the same step on the exact-fp32 MFMA path, for reference beside the default bf16x3 split
