@@ -42,7 +42,9 @@ BIG_LAMA = dict(
     init_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
     downsample_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
     resnet_conv_kwargs=dict(ratio_gin=0.75, ratio_gout=0.75, enable_lfu=False))
-BATCH, RES = 8, 512
+BATCH, RES = 8, 512            # BASELINE configs[1]; LAMA_BENCH_BATCH / LAMA_BENCH_RES override them for exploratory runs only
+BATCH = int(os.environ.get('LAMA_BENCH_BATCH', BATCH))
+RES = int(os.environ.get('LAMA_BENCH_RES', RES))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0
@@ -239,7 +241,7 @@ def main():
             gbs = alg / kern[fu]['avg_us'] / 1e3
             parts = [pmc_traffic(k, args.precision) for k in ('rfft2_192x64x64', 'conv1x1_cin384_cout384_64x33', 'irfft2_192x64x64')]
             ffc_traffic = sum(p_['traffic_bytes'] for p_ in parts) if all(parts) else None
-            roof_ffc = dict(unit_of_work='FourierUnit forward [8,192,64,64] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
+            roof_ffc = dict(unit_of_work=f'FourierUnit forward [{BATCH},192,{h},{h}] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
                             peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=ffc_traffic,
                             avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg)
 
@@ -269,11 +271,11 @@ def main():
     if rank == 0:
         total_images = world * BATCH * args.steps
         line = {
-            'metric': 'inpainted images/sec at 512x512 big-lama',
+            'metric': f'inpainted images/sec at {RES}x{RES} big-lama',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if precision == L.PREC_F32 else f'f32 (3-term {args.precision[:-2]} split on the 16-bit MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',
-            'config': {'workload': f'big-lama FFCResNetGenerator 512x512 batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
+            'config': {'workload': f'big-lama FFCResNetGenerator {RES}x{RES} batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
                                    f'mask-compose + generator + blend + u8, random-init weights',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'hip_graph': not args.no_graph, 'precision': args.precision},
