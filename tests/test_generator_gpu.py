@@ -133,3 +133,45 @@ def test_odd_sized_input_generic_fft(big):
     with torch.no_grad():
         ref = O.generator_forward(x, sd, cfg)
     assert float((gen(x.cuda()).cpu() - ref).abs().max()) < TOL
+
+
+def test_predict_cli_end_to_end(tmp_path):
+    """python -m lama_amd.predict on a checkpoint directory (config.yaml with unresolved interpolations + models/best.ckpt) and a
+    folder of PNGs: same on-disk contract as bin/predict.py; results within 1 u8 level of the oracle's batch-1 predict loop."""
+    import yaml
+    from PIL import Image
+    from lama_amd import predict as P
+    cfg = O.small_config(ngf=16, n_blocks=2)
+    sd = O.make_synthetic_state_dict(cfg, seed=5, calib_hw=32)
+    raw = dict(training_model=dict(kind='default', concat_mask=True),
+               generator=dict(kind='ffc_resnet', **{k: v for k, v in cfg.items() if not isinstance(v, dict)},
+                              init_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
+                              downsample_conv_kwargs=dict(ratio_gin='${generator.init_conv_kwargs.ratio_gout}',
+                                                          ratio_gout='${generator.downsample_conv_kwargs.ratio_gin}', enable_lfu=False),
+                              resnet_conv_kwargs=dict(ratio_gin=0.75, ratio_gout='${generator.resnet_conv_kwargs.ratio_gin}', enable_lfu=False)))
+    mdir = tmp_path / 'model'
+    os.makedirs(mdir / 'models')
+    with open(mdir / 'config.yaml', 'w') as f:
+        yaml.safe_dump(raw, f)
+    torch.save({'state_dict': {**{'generator.' + k: v for k, v in sd.items()}, 'discriminator.x': torch.zeros(2)}}, mdir / 'models' / 'best.ckpt')
+    rng = np.random.RandomState(3)
+    indir = tmp_path / 'in'
+    os.makedirs(indir / 'sub')
+    shapes = [(100, 136), (128, 128), (100, 136)]
+    for i, (h, w) in enumerate(shapes):
+        d = indir / ('sub' if i == 2 else '')
+        Image.fromarray(rng.randint(0, 256, (h, w, 3)).astype('uint8')).save(d / f'im{i}.png')
+        m = np.zeros((h, w), 'uint8')
+        m[h // 3: 2 * h // 3, w // 4: w // 2] = 255
+        Image.fromarray(m).save(d / f'im{i}_mask001.png')
+    out = tmp_path / 'out'
+    assert P.main([f'model.path={mdir}', f'indir={indir}', f'outdir={out}', 'batch_size=2']) == 0
+    items = P.list_dataset(str(indir) + os.sep, '.png')
+    assert len(items) == 3
+    sdg = {'generator.' + k: v for k, v in sd.items()}
+    for mask_path, img_path in items:
+        rel = os.path.splitext(mask_path[len(str(indir)) + 1:])[0] + '.png'
+        got = np.array(Image.open(out / rel))
+        _, u8 = O.predict_one(O.load_image(img_path, 'RGB'), O.load_image(mask_path, 'L'), sdg, cfg)
+        assert got.shape == u8.shape
+        assert np.abs(got.astype(int) - u8.astype(int)).max() <= 1, rel
