@@ -22,6 +22,7 @@
 #include "common.h"
 
 #define FFT_SQRT1_2 0.70710678118654752440f
+__device__ __forceinline__ int lama_ceil_div_dev(int a, int b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
@@ -478,8 +479,141 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_inv_kernel(FftParams p
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// two-pass path: power-of-two planes larger than one workgroup's LDS (256 x 256 ... 1024 x 1024, or one long side):
+// row FFTs and column FFTs as two launches through the complex workspace ws[plane][h][wf].  Same butterflies (fft_lds) and
+// the same row-pair packing as the one-pass kernels; the DC / Nyquist columns are simply transformed like every other
+// column (wf = w/2 + 1 column FFTs instead of w/2).
+// ------------------------------------------------------------------------------------------------
+#define FFT2P_PAIRS 8   // row pairs per workgroup (pass R)
+#define FFT2P_COLS 8    // columns per workgroup (pass C)
+
+// forward rows: ws[plane][y][k] = half spectrum of row y (unscaled)
+__global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_fwd_kernel(FftParams p, float2* ws) {
+    const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
+    const int RSW = w + 1;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tw + w;
+    float2* Q = P + FFT2P_PAIRS * RSW;
+    const int tid = threadIdx.x;
+    const int gpp = lama_ceil_div_dev(hh, FFT2P_PAIRS);          // pair groups per plane
+    const int plane = blockIdx.x / gpp, f0 = (blockIdx.x - plane * gpp) * FFT2P_PAIRS;
+    const int np = (hh - f0) < FFT2P_PAIRS ? (hh - f0) : FFT2P_PAIRS;
+    const int b = plane / p.C, c = plane - b * p.C;
+    fft_init_twiddles<false>(tw, w);
+    const float* src = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+    for (int i = tid; i < np * w; i += LAMA_NTHREADS) {
+        int f = i / w, n = i - f * w;
+        P[f * RSW + n] = make_float2(src[(long long)(2 * (f0 + f)) * w + n], src[(long long)(2 * (f0 + f) + 1) * w + n]);
+    }
+    __syncthreads();
+    float2* E = fft_lds<false>(P, Q, tw, w, np, 1, RSW, np, 0);
+    float2* out = ws + (long long)plane * h * wf;
+    for (int i = tid; i < np * wf; i += LAMA_NTHREADS) {
+        int f = i / wf, k = i - f * wf;
+        const float2* z = E + f * RSW;
+        float2 za, zb;
+        if (k == 0) { za = make_float2(z[0].x, 0.f); zb = make_float2(z[0].y, 0.f); }
+        else if (k == wh) { za = make_float2(z[wh].x, 0.f); zb = make_float2(z[wh].y, 0.f); }
+        else {
+            float2 zk = z[k], zm = z[w - k];
+            za = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            zb = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        }
+        out[(long long)(2 * (f0 + f)) * wf + k] = za;
+        out[(long long)(2 * (f0 + f) + 1) * wf + k] = zb;
+    }
+}
+
+// columns: forward (INV = false): spec[u][k] = scale * FFT_h(ws[.][k]); inverse: ws[y][k] = IFFT_h(spec[.][k]) (unscaled)
+template <bool INV>
+__global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_cols_kernel(FftParams p, float2* ws) {
+    const int h = p.h, wf = p.wf;
+    const int CS = h + 1;                                        // LDS pitch of one column
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tw + h;
+    float2* Q = P + FFT2P_COLS * CS;
+    const int tid = threadIdx.x;
+    const int ncb = lama_ceil_div_dev(wf, FFT2P_COLS);
+    const int plane = blockIdx.x / ncb, k0 = (blockIdx.x - plane * ncb) * FFT2P_COLS;
+    const int nc = (wf - k0) < FFT2P_COLS ? (wf - k0) : FFT2P_COLS;
+    const int b = plane / p.C, c = plane - b * p.C;
+    const long long per_plane = (long long)h * wf;
+    float* sre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    float* sim = sre + per_plane;
+    float2* wp = ws + (long long)plane * per_plane;
+    fft_init_twiddles<INV>(tw, h);
+    for (int i = tid; i < h * FFT2P_COLS; i += LAMA_NTHREADS) {
+        int y = i / FFT2P_COLS, kk = i - y * FFT2P_COLS;
+        if (kk < nc) {
+            long long o = (long long)y * wf + k0 + kk;
+            P[kk * CS + y] = INV ? make_float2(sre[o], sim[o]) : wp[o];
+        }
+    }
+    __syncthreads();
+    float2* E = fft_lds<INV>(P, Q, tw, h, nc, 1, CS, nc, 0);
+    for (int i = tid; i < h * FFT2P_COLS; i += LAMA_NTHREADS) {
+        int u = i / FFT2P_COLS, kk = i - u * FFT2P_COLS;
+        if (kk < nc) {
+            long long o = (long long)u * wf + k0 + kk;
+            float2 v = E[kk * CS + u];
+            if (INV) wp[o] = v;
+            else { sre[o] = v.x * p.scale; sim[o] = v.y * p.scale; }
+        }
+    }
+}
+
+// inverse rows: c2r of ws rows (Im of bins 0 and w/2 ignored), two rows per complex FFT, fused residual add
+__global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_inv_kernel(FftParams p, const float2* ws) {
+    const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
+    const int RSW = w + 1;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tw + w;
+    float2* Q = P + FFT2P_PAIRS * RSW;
+    const int tid = threadIdx.x;
+    const int gpp = lama_ceil_div_dev(hh, FFT2P_PAIRS);
+    const int plane = blockIdx.x / gpp, f0 = (blockIdx.x - plane * gpp) * FFT2P_PAIRS;
+    const int np = (hh - f0) < FFT2P_PAIRS ? (hh - f0) : FFT2P_PAIRS;
+    const int b = plane / p.C, c = plane - b * p.C;
+    fft_init_twiddles<true>(tw, w);
+    const float2* in = ws + (long long)plane * h * wf;
+    for (int i = tid; i < np * wf; i += LAMA_NTHREADS) {
+        int f = i / wf, k = i - f * wf;
+        float2 za = in[(long long)(2 * (f0 + f)) * wf + k], zb = in[(long long)(2 * (f0 + f) + 1) * wf + k];
+        float2* z = P + f * RSW;
+        if (k == 0 || k == wh) z[k] = make_float2(za.x, zb.x);
+        else {
+            z[k] = make_float2(za.x - zb.y, za.y + zb.x);
+            z[w - k] = make_float2(za.x + zb.y, zb.x - za.y);
+        }
+    }
+    __syncthreads();
+    float2* E = fft_lds<true>(P, Q, tw, w, np, 1, RSW, np, 0);
+    const long long base = (long long)c * h * w;
+    for (int i = tid; i < np * w; i += LAMA_NTHREADS) {
+        int f = i / w, n = i - f * w;
+        float2 v = E[f * RSW + n];
+        long long oa = base + (long long)(2 * (f0 + f)) * w + n, ob = oa + w;
+        float ra = v.x * p.scale, rb = v.y * p.scale;
+        if (p.x) {
+            const float* r = p.x + (long long)b * p.x_bstride;
+            ra += r[oa];
+            rb += r[ob];
+        }
+        float* d = p.y + (long long)b * p.y_bstride;
+        d[oa] = ra;
+        d[ob] = rb;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 namespace {
+
+// two-pass LDS FFT: power-of-two planes the one-pass kernels cannot hold
+bool fft_two_pass_ok(int h, int w) {
+    return lama_is_pow2(h) && lama_is_pow2(w) && h >= 16 && w >= 16 && h <= 1024 && w <= 1024 && (h > 128 || w > 128);
+}
 
 bool fft_fast_ok(int h, int w) { return lama_is_pow2(h) && lama_is_pow2(w) && h >= 16 && w >= 16 && h <= 128 && w <= 128; }
 
@@ -541,6 +675,15 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
+    if (fft_two_pass_ok(p.h, p.w)) {
+        size_t ldsr = ((size_t)p.w + 2 * (size_t)FFT2P_PAIRS * (p.w + 1)) * sizeof(float2);
+        size_t ldsc = ((size_t)p.h + 2 * (size_t)FFT2P_COLS * (p.h + 1)) * sizeof(float2);
+        hipLaunchKernelGGL(fft2p_rows_fwd_kernel, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, ws);
+        LAMA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(fft2p_cols_kernel<false>, dim3(p.nplanes * lama_ceil_div(p.wf, FFT2P_COLS)), dim3(LAMA_NTHREADS), ldsc, st, p, ws);
+        LAMA_CHECK_LAUNCH();
+        return LAMA_OK;
+    }
     long long nrows = (long long)p.nplanes * p.h;
     size_t lds1 = (size_t)p.w * sizeof(float2) + (size_t)DFT_ROWS_PER_WG * p.w * sizeof(float);
     size_t lds2 = (size_t)p.h * sizeof(float2) * (1 + DFT_COLS_PER_WG);
@@ -587,6 +730,15 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
+    if (fft_two_pass_ok(p.h, p.w)) {
+        size_t ldsr = ((size_t)p.w + 2 * (size_t)FFT2P_PAIRS * (p.w + 1)) * sizeof(float2);
+        size_t ldsc = ((size_t)p.h + 2 * (size_t)FFT2P_COLS * (p.h + 1)) * sizeof(float2);
+        hipLaunchKernelGGL(fft2p_cols_kernel<true>, dim3(p.nplanes * lama_ceil_div(p.wf, FFT2P_COLS)), dim3(LAMA_NTHREADS), ldsc, st, p, ws);
+        LAMA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(fft2p_rows_inv_kernel, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, (const float2*)ws);
+        LAMA_CHECK_LAUNCH();
+        return LAMA_OK;
+    }
     long long nrows = (long long)p.nplanes * p.h;
     size_t lds1 = (size_t)p.w * sizeof(float2) + (size_t)DFT_ROWS_PER_WG * p.wf * sizeof(float2);
     size_t lds2 = (size_t)p.h * sizeof(float2) * (1 + DFT_COLS_PER_WG);

@@ -109,7 +109,8 @@ def _inv_ref(spec, h, w):
 
 
 FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32),   # fused LDS path
-             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13)]          # generic DFT path
+             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13),          # generic DFT path
+             (256, 32), (16, 512), (256, 256)]                                # two-pass LDS path
 
 
 @pytest.mark.parametrize('hw', FFT_SIZES, ids=lambda s: f'{s[0]}x{s[1]}')
@@ -125,17 +126,18 @@ def test_rfft2_irfft2_emulated(hw):
     ws = torch.zeros(max(nws, 4) // 4)
     lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, ws)
     ref = _spec_ref(x)
-    assert torch.allclose(spec, ref, atol=3e-5, rtol=1e-4), float((spec - ref).abs().max())
+    tol = 3e-5 if max(h, w) <= 128 else 1e-4
+    assert torch.allclose(spec, ref, atol=tol, rtol=1e-4), float((spec - ref).abs().max())
     # inverse on a NON-Hermitian spectrum (as after conv+BN+ReLU), fused residual add
     spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g))
     resid = torch.randn(B, Cn, h, w, generator=g)
     y = torch.zeros(B, Cn, h, w)
     lib.irfft2(L.view(spec2), L.view(resid), L.view(y), B, ws)
     ref2 = resid + _inv_ref(spec2, h, w)
-    assert torch.allclose(y, ref2, atol=3e-5, rtol=1e-4), float((y - ref2).abs().max())
+    assert torch.allclose(y, ref2, atol=tol, rtol=1e-4), float((y - ref2).abs().max())
     y2 = torch.zeros(B, Cn, h, w)
     lib.irfft2(L.view(spec2), None, L.view(y2), B, ws)
-    assert torch.allclose(y2, ref2 - resid, atol=3e-5, rtol=1e-4)
+    assert torch.allclose(y2, ref2 - resid, atol=tol, rtol=1e-4)
 
 
 def test_fourier_unit_emulated():
