@@ -179,6 +179,7 @@ def main():
     timer = KernelTimer(lib)
     model = build_model(device, precision)
     model.generator.use_graph = not args.no_graph
+    model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '0')))   # experimental, see lama_amd/ffc.py
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
     gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if world > 1 else None
@@ -250,7 +251,6 @@ def main():
     if rank == 0 and world == 1 and precision != L.PREC_F32 and not args.no_f32_leg:
         model.generator.set_precision(L.PREC_F32)
         model.generator.use_graph = not args.no_graph
-        model.generator.overlap_streams = True
         for _ in range(2):
             step()
         torch.cuda.synchronize()
