@@ -175,3 +175,13 @@ def test_predict_cli_end_to_end(tmp_path):
         _, u8 = O.predict_one(O.load_image(img_path, 'RGB'), O.load_image(mask_path, 'L'), sdg, cfg)
         assert got.shape == u8.shape
         assert np.abs(got.astype(int) - u8.astype(int)).max() <= 1, rel
+
+
+def test_long_plane_two_pass_fft(big):
+    """1 x 2048 x 256 input -> bottleneck planes 256 x 32: the two-pass LDS FFT (rows, then columns) inside the full generator."""
+    cfg, sd, gen, TOL = big
+    batch = O.make_synthetic_batch(1, 2048, 256, seed=8)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        ref = O.generator_forward(x, sd, cfg)
+    assert float((gen(x.cuda()).cpu() - ref).abs().max()) < TOL
