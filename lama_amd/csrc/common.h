@@ -45,6 +45,24 @@ __device__ __forceinline__ int lama_xcd_remap(int orig, int nwg) {
 #define LAMA_KEEP_LIVE(x) asm volatile("" ::"v"(x))
 #endif
 
+// Raw buffer loads: 128-bit resource (base, byte size) in SGPRs + 32-bit lane offset + 32-bit scalar offset.  One address
+// VGPR serves any number of loads that differ only in the (uniform) scalar offset, and out-of-range offsets read 0.
+// (tests/hipemu overrides these for the host build.)
+#ifndef LAMA_BUF_RSRC
+typedef __amdgpu_buffer_rsrc_t lama_buf_t;
+// the descriptor inputs go through readfirstlane so that hipcc can PROVE them wave-uniform (otherwise every buffer op is
+// wrapped in a waterfall loop: cdna_hip_programming.md T20)
+__device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long bytes) {
+    const unsigned long long a = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+#define LAMA_BUF_RSRC(ptr, bytes) lama_make_buf(ptr, bytes)
+#define LAMA_BUF_LOAD_B32(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)
+#define LAMA_BUF_LOAD_B128(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0)
+#define LAMA_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 // 3-term split convolution back ends (conv_split3.inc compiled as conv_bf16x3.hip / conv_f16x3.hip), reached through
 // lama_conv2d_* with LAMA_PREC_BF16X3 / LAMA_PREC_F16X3
 #define LAMA_CB_DECL(sfx)                                                                                                        \

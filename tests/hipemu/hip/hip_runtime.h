@@ -112,6 +112,7 @@ extern __attribute__((aligned(16))) char lama_smem[];
 static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
@@ -241,6 +242,26 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(V8 a, V8 b, hipemu_f32x
 #define LAMA_KEEP_LIVE(x) ((void)(x))
 static inline void hipemu_global_load_lds(const void* g, void* l, int size) { memcpy((char*)l + hipemu::lane() * size, g, size); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu_global_load_lds((const char*)(g) + (off), l, size)
+
+// raw buffer loads (common.h): base + byte size, lane offset + scalar offset, out-of-range reads return 0
+struct lama_buf_t { const char* p; unsigned long long n; };
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+static inline unsigned hipemu_buf_load_b32(lama_buf_t r, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    unsigned v = 0;
+    if (o + 4 <= r.n) memcpy(&v, r.p + o, 4);
+    return v;
+}
+static inline hipemu_u32x4 hipemu_buf_load_b128(lama_buf_t r, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    hipemu_u32x4 v = {0, 0, 0, 0};
+    if (o + 16 <= r.n) memcpy(&v, r.p + o, 16);
+    return v;
+}
+#define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
+#define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)
+#define LAMA_BUF_LOAD_B128(rsrc, voff, soff) hipemu_buf_load_b128(rsrc, voff, soff)
+#define LAMA_WAVE_UNIFORM(x) (x)
 
 // math helpers that exist in HIP device code
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }

@@ -44,6 +44,11 @@ CONV_CASES = [
     dict(cin=24, cout=192, k=1, stride=1, pad=0, H=9, W=16, act=1, bias=True, resid=False, scale=True),     # 192-row M tiles (bf16x3)
     dict(cin=20, cout=384, k=3, stride=1, pad=1, H=6, W=36, act=1, bias=True, resid=True, scale=False),
     dict(cin=24, cout=70, k=3, stride=2, pad=1, H=9, W=34, act=1, bias=True, resid=False, scale=True, transposed=True),   # fused classes, BM=128
+    # weights-in-registers kernels (conv_wreg_dev.inc): 3x3 with cin % 32 == 0 / 1x1 with cin % 64 == 0, cout >= 96
+    dict(cin=64, cout=130, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True),      # ragged tiles, 2 M tiles
+    dict(cin=32, cout=96, k=3, stride=1, pad=1, H=5, W=6, act=0, bias=False, resid=False, scale=False),    # one chunk, narrow image
+    dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),    # flat 1x1, two chunks
+    dict(cin=192, cout=200, k=1, stride=1, pad=0, H=12, W=11, act=2, bias=True, resid=False, scale=False),  # odd chunk count
 ]
 
 
@@ -94,6 +99,26 @@ def test_conv2d_fused_second_operand_emulated(prec):
                False, bias, L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale, precision=prec),
                precision=prec)
     assert torch.allclose(out[:, cl:], ref, **CONV_TOL[prec]), float((out[:, cl:] - ref).abs().max())
+
+
+@pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
+def test_conv2d_fused_second_operand_wreg_emulated(prec):
+    """Same fused launch at channel counts that take the weights-in-registers kernel (3x3 cin % 32 == 0 + 1x1 cin % 64 == 0)."""
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(3)
+    B, cl, cg, half, H, W = 2, 32, 160, 64, 6, 35
+    state = torch.randn(B, cl + cg, H, W, generator=g)
+    t = torch.randn(B, half, H, W, generator=g)
+    w1 = torch.randn(cg, cl, 3, 3, generator=g) * 0.2
+    w2 = torch.randn(cg, half, 1, 1, generator=g) * 0.2
+    scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
+    ref = _conv_ref(state[:, :cl], w1, 1, 1, True, False, bias, 1, state[:, cl:], x2=t, w2=w2 * scale[:, None, None, None], scale=scale)
+    out = torch.zeros_like(state)
+    lib.conv2d(L.view(state, 0, cl), lib.pack_conv_weight(w1, scale, precision=prec), L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT,
+               False, bias, L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale, precision=prec),
+               precision=prec)
+    assert torch.allclose(out[:, cl:], ref, **CONV_TOL[prec]), float((out[:, cl:] - ref).abs().max())
+    assert float(out[:, :cl].abs().max()) == 0.0
 
 
 def _spec_ref(x):

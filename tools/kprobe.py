@@ -21,8 +21,10 @@ def main():
     g = torch.Generator().manual_seed(0)
     B, h, w = 8, 64, 64
 
+    zero = os.environ.get('KPROBE_ZERO', '0') == '1'   # all-zero operands: how much of the time is power (operand toggling)?
+
     def rnd(*s):
-        return torch.randn(*s, generator=g).to(dev)
+        return torch.zeros(*s, device=dev) if zero else torch.randn(*s, generator=g).to(dev)
 
     def conv(cin, cout, k, H, W, stride=1, tr=False, x2c=0):
         x = rnd(B, cin, H, W)
