@@ -101,12 +101,13 @@ def test_conv2d_fused_second_operand_emulated(prec):
     assert torch.allclose(out[:, cl:], ref, **CONV_TOL[prec]), float((out[:, cl:] - ref).abs().max())
 
 
+@pytest.mark.parametrize('cg_', [160, 384], ids=['cg160', 'cg384'])   # 384: all rows in one 12-wave workgroup
 @pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
-def test_conv2d_fused_second_operand_wreg_emulated(prec):
+def test_conv2d_fused_second_operand_wreg_emulated(prec, cg_):
     """Same fused launch at channel counts that take the weights-in-registers kernel (3x3 cin % 32 == 0 + 1x1 cin % 64 == 0)."""
     lib = emu_lib()
     g = torch.Generator().manual_seed(3)
-    B, cl, cg, half, H, W = 2, 32, 160, 64, 6, 35
+    B, cl, cg, half, H, W = 2, 32, cg_, 64, 6, 35
     state = torch.randn(B, cl + cg, H, W, generator=g)
     t = torch.randn(B, half, H, W, generator=g)
     w1 = torch.randn(cg, cl, 3, 3, generator=g) * 0.2
