@@ -61,6 +61,13 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0)
 #define LAMA_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#define LAMA_CLOCK() ((long long)wall_clock64())   // 100 MHz constant counter (timeline traces of the profiling tools)
+#endif
+
+// make a per-lane integer opaque to the optimiser at this point of the program (pins the loads that depend on it behind the
+// code above: epilogue loads must not be hoisted over the main loop, where their registers are needed)
+#ifndef LAMA_OPAQUE
+#define LAMA_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
 // 3-term split convolution back ends (conv_split3.inc compiled as conv_bf16x3.hip / conv_f16x3.hip), reached through

@@ -240,6 +240,7 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(V8 a, V8 b, hipemu_f32x
 // LDS-DMA: every lane copies `size` bytes from its own global address to (wave-uniform LDS base + lane*size)
 #define LAMA_LDS_PTR(p) ((void*)(p))
 #define LAMA_KEEP_LIVE(x) ((void)(x))
+#define LAMA_OPAQUE(x) ((void)(x))
 static inline void hipemu_global_load_lds(const void* g, void* l, int size) { memcpy((char*)l + hipemu::lane() * size, g, size); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu_global_load_lds((const char*)(g) + (off), l, size)
 
@@ -262,6 +263,7 @@ static inline hipemu_u32x4 hipemu_buf_load_b128(lama_buf_t r, unsigned voff, uns
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) hipemu_buf_load_b128(rsrc, voff, soff)
 #define LAMA_WAVE_UNIFORM(x) (x)
+#define LAMA_CLOCK() 0ll
 
 // math helpers that exist in HIP device code
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of the weights-in-registers kernels (LAMA_CW_TRACE).  usage: wr_trace.py [convA|fuconv]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+name = sys.argv[1] if len(sys.argv) > 1 else 'fuconv'
+buf = torch.zeros(4096 * 32, dtype=torch.int64, device='cuda')
+os.environ['LAMA_CW_TRACE'] = hex(buf.data_ptr())
+from lama_amd import _lib as L  # noqa: E402
+
+lib = L.get_lib()
+prec = L.PREC_F16X3
+st = torch.cuda.current_stream().cuda_stream
+B = 8
+g = torch.Generator().manual_seed(0)
+cin, cout, k, H, W = (512, 128, 3, 64, 64) if name == 'convA' else (384, 384, 1, 64, 33)
+x = torch.randn(B, cin, H, W, generator=g).cuda()
+wt = torch.randn(cout, cin, k, k, generator=g).cuda()
+wp = lib.pack_conv_weight(wt, None, stride=1, transposed=False, precision=prec)
+y = torch.empty(B, cout, H, W, device='cuda')
+bias = torch.randn(cout, generator=g).cuda()
+for _ in range(5):
+    lib.conv2d(L.view(x), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bias, L.ACT_RELU, None, None, None, precision=prec, stream=st)
+torch.cuda.synchronize()
+buf.zero_()
+torch.cuda.synchronize()
+lib.conv2d(L.view(x), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bias, L.ACT_RELU, None, None, None, precision=prec, stream=st)
+torch.cuda.synchronize()
+t = buf.view(-1, 32).cpu()
+t = t[t[:, 0] > 0]
+t0 = int(t[:, 0].min())
+nch = int(((t[:, 2:30] > 0).sum(1)).max())
+print(f'{name}: {t.shape[0]} workgroups, {nch} chunks; times in us relative to the first workgroup start (100 MHz ticks)')
+rel = (t.double() - t0) / 100.0
+start, pro, end = rel[:, 0], rel[:, 1] - rel[:, 0], rel[:, 30] - rel[:, 0]
+last = rel[:, 1 + nch]
+print(f'start   : min {start.min():.2f} median {start.median():.2f} max {start.max():.2f}')
+print(f'prologue: median {pro.median():.2f} max {pro.max():.2f}')
+ch = (rel[:, 2:2 + nch] - rel[:, 1:1 + nch])
+print('chunks  : median per chunk ' + ' '.join(f'{v:.2f}' for v in ch.median(0).values.tolist()))
+print(f'epilogue: median {(rel[:, 30] - last).median():.2f} max {(rel[:, 30] - last).max():.2f}')
+print(f'workgroup total: median {end.median():.2f} max {end.max():.2f}; last end {rel[:, 30].max():.2f}')
+late = t[start > start.median() + 1.0].shape[0]
+print(f'workgroups starting > 1 us after the median start (second round): {late}')
