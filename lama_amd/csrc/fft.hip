@@ -137,6 +137,7 @@ struct FftParams {
     int nplanes;         // B*C
     int ppw;             // planes per workgroup
     float scale;         // 1/sqrt(h*w)
+    long long* trace;    // profiling tools only (LAMA_FFT_TRACE): 16 int64 per workgroup, 100 MHz ticks at the phase boundaries
 };
 
 template <bool INV>
@@ -162,8 +163,14 @@ __device__ __forceinline__ void rowpair_item(int item, int wq, int& f, int& q) {
 
 // HT / WT: compile-time plane size (0 = take it from the parameters).  With constant sizes every div / mod of the item
 // decomposition folds to shifts and the pass loops unroll -- the generic instantiation is VALU-bound on that index math.
-template <int HT, int WT, int PPW>
+// SEQ > 1 (sized instantiations with one plane in LDS): the workgroup walks SEQ consecutive planes and requests plane s + 1
+// from HBM (into registers) before it transforms plane s, so only the first plane's load latency is exposed, the twiddles are
+// set up once, and a launch of B*C planes is B*C / SEQ workgroups that are all resident at once (no tail round).
+#define FFT_STAMP(i) do { if constexpr (TR) { if (threadIdx.x == 0) p.trace[(long long)blockIdx.x * 16 + (i)] = LAMA_CLOCK(); } } while (0)
+template <int HT, int WT, int PPW, int SEQ = 1, bool TR = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
+    FFT_STAMP(0);
+    static_assert(SEQ == 1 || (HT > 0 && WT > 0 && PPW == 1), "sequential planes: sized one-plane instantiations only");
     const int h = HT ? HT : p.h, w = WT ? WT : p.w, wf = w / 2 + 1, hh = h >> 1, wh = w >> 1;
     const int RSW = w + 1;
     const int bufsz = (PPW ? PPW : p.ppw) * (hh * RSW > h * wf ? hh * RSW : h * wf);
@@ -173,13 +180,49 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
     float2* Q = P + bufsz;
     const int tid = threadIdx.x;
     const int ppw = PPW ? PPW : p.ppw;   // the sized instantiations are only launched when ppw divides the plane count
-    const int plane0 = blockIdx.x * ppw;
-    const int np = PPW ? PPW : ((p.nplanes - plane0) < ppw ? (p.nplanes - plane0) : ppw);
+    const int np = PPW ? PPW : ((p.nplanes - (int)blockIdx.x * ppw) < ppw ? (p.nplanes - (int)blockIdx.x * ppw) : ppw);
 
     fft_init_twiddles<false>(tww, w);
     fft_init_twiddles<false>(twh, h);
+    // row-pair prefetch registers of the sequential variant
+    constexpr int NPF = SEQ > 1 ? ((HT / 2) * (WT / 4) + LAMA_NTHREADS - 1) / LAMA_NTHREADS : 1;
+    float4 pra[NPF], prb[NPF];
+    auto prefetch = [&](int plane) {
+        const int b = plane / p.C, c = plane - b * p.C;
+        const float* base = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            if (item < hh * (w >> 2)) {
+                int f, q;
+                rowpair_item(item, w >> 2, f, q);
+                const float* src = base + (2 * f) * w + q * 4;
+                pra[it] = *reinterpret_cast<const float4*>(src);
+                prb[it] = *reinterpret_cast<const float4*>(src + w);
+            }
+        }
+    };
+    if constexpr (SEQ > 1) prefetch(blockIdx.x * SEQ);
+#pragma unroll 1
+    for (int sq = 0; sq < SEQ; ++sq) {
+    const int plane0 = (blockIdx.x * SEQ + sq) * ppw;
     // 1. load row pairs: P[pl][f][n] = (x[2f][n], x[2f+1][n])
-    {
+    if constexpr (SEQ > 1) {
+#pragma unroll
+        for (int it = 0; it < NPF; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            if (item < hh * (w >> 2)) {
+                int f, q;
+                rowpair_item(item, w >> 2, f, q);
+                float2* d = P + f * RSW + q * 4;
+                d[0] = make_float2(pra[it].x, prb[it].x);
+                d[1] = make_float2(pra[it].y, prb[it].y);
+                d[2] = make_float2(pra[it].z, prb[it].z);
+                d[3] = make_float2(pra[it].w, prb[it].w);
+            }
+        }
+        if (sq + 1 < SEQ) prefetch(plane0 + 1);
+    } else {
         const int wq = w >> 2;
         const int per_plane = hh * wq;
         for (int item = tid; item < np * per_plane; item += LAMA_NTHREADS) {
@@ -198,8 +241,10 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
         }
     }
     __syncthreads();
+    FFT_STAMP(1);
     // 2. row FFTs (length w) of the packed row pairs
     float2* E1 = fft_lds<false>(P, Q, tww, w, np * hh, 1, RSW, np * hh, 0);
+    FFT_STAMP(2);
     float2* S = (E1 == P) ? Q : P;  // spectrum buffer, [pl][h][wf]
     // 3. untangle the pairs into the half spectra of the two rows; column 0 packs (DC, Nyquist)
     for (int item = tid; item < np * hh * wh; item += LAMA_NTHREADS) {
@@ -219,9 +264,36 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
         }
     }
     __syncthreads();
+    FFT_STAMP(3);
     // 4. column FFTs (length h) over columns 0..w/2-1 of every plane
     //    FFT index = (plane, column): inner stride 1 (column), outer stride h*wf (plane)
     float2* E2 = fft_lds<false>(S, E1, twh, h, np * wh, wf, 1, wh, h * wf);
+    FFT_STAMP(4);
+    if constexpr (SEQ > 1) {
+        // 5 + 6 in one phase: float4 stores of the Re / Im planes; the DC (col 0) and Nyquist (col w/2) values are untangled
+        // from the packed column 0 on the fly (two extra LDS reads for 2 of the wf columns), which saves two barriers
+        const int per_plane = h * wf;
+        const int b = plane0 / p.C, c = plane0 - b * p.C;
+        float* dre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
+            float re[4], im[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i4 * 4 + e;
+                const int k = i / wf, col = i - k * wf;
+                float2 v = E2[i];
+                if (col == 0 || col == wh) {
+                    const float2 cc = E2[k * wf], cm = E2[((h - k) & (h - 1)) * wf];
+                    v = col == 0 ? make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y)) : make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
+                }
+                re[e] = v.x * p.scale;
+                im[e] = v.y * p.scale;
+            }
+            *reinterpret_cast<float4*>(dre + i4 * 4) = make_float4(re[0], re[1], re[2], re[3]);
+            *reinterpret_cast<float4*>(dre + per_plane + i4 * 4) = make_float4(im[0], im[1], im[2], im[3]);
+        }
+        if (sq + 1 < SEQ) __syncthreads();   // the next plane's row pairs overwrite the buffers
+    } else {
     // 5. untangle column 0 into the DC (col 0) and Nyquist (col w/2) columns
     {
         float2 x0 = make_float2(0.f, 0.f), xn = x0;
@@ -239,6 +311,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
         }
     }
     __syncthreads();
+    FFT_STAMP(5);
     // 6. store the Re / Im planes (channels 2c, 2c+1), ortho scale
     {
         const int per_plane = h * wf;
@@ -252,10 +325,17 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
             dst[per_plane] = v.y * p.scale;
         }
     }
+    }
+    }   // planes of this workgroup
+    FFT_STAMP(6);
 }
 
-template <int HT, int WT, int PPW>
+// SEQ > 1: as in rfft2_lds_kernel -- SEQ consecutive planes per workgroup, the spectrum of plane s + 1 (float4 loads of the Re / Im
+// planes) is requested before plane s is transformed, and the residual of plane s right behind its own spectrum (not at store time).
+template <int HT, int WT, int PPW, int SEQ = 1, bool TR = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) {
+    FFT_STAMP(0);
+    static_assert(SEQ == 1 || (HT > 0 && WT > 0 && PPW == 1), "sequential planes: sized one-plane instantiations only");
     const int h = HT ? HT : p.h, w = WT ? WT : p.w, wf = w / 2 + 1, hh = h >> 1, wh = w >> 1;
     const int RSW = w + 1;
     const int bufsz = (PPW ? PPW : p.ppw) * (hh * RSW > h * wf ? hh * RSW : h * wf);
@@ -265,13 +345,60 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
     float2* Q = P + bufsz;
     const int tid = threadIdx.x;
     const int ppw = PPW ? PPW : p.ppw;   // the sized instantiations are only launched when ppw divides the plane count
-    const int plane0 = blockIdx.x * ppw;
-    const int np = PPW ? PPW : ((p.nplanes - plane0) < ppw ? (p.nplanes - plane0) : ppw);
+    const int np = PPW ? PPW : ((p.nplanes - (int)blockIdx.x * ppw) < ppw ? (p.nplanes - (int)blockIdx.x * ppw) : ppw);
     const int per_plane = h * wf;
 
     fft_init_twiddles<true>(tww, w);
     fft_init_twiddles<true>(twh, h);
+    constexpr int NSP = SEQ > 1 ? (HT * (WT / 2 + 1) / 4 + LAMA_NTHREADS - 1) / LAMA_NTHREADS : 1;    // float4 items of one spectrum plane
+    constexpr int NRP = SEQ > 1 ? ((HT / 2) * (WT / 4) + LAMA_NTHREADS - 1) / LAMA_NTHREADS : 1;       // row-pair items of one output plane
+    float4 sre[NSP], sim[NSP], rxa[NRP], rxb[NRP];
+    auto prefetch_spec = [&](int plane) {
+        const int b = plane / p.C, c = plane - b * p.C;
+        const float* base = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+#pragma unroll
+        for (int it = 0; it < NSP; ++it) {
+            const int i4 = tid + it * LAMA_NTHREADS;
+            if (i4 < per_plane / 4) {
+                sre[it] = *reinterpret_cast<const float4*>(base + i4 * 4);
+                sim[it] = *reinterpret_cast<const float4*>(base + per_plane + i4 * 4);
+            }
+        }
+    };
+    auto prefetch_resid = [&](int plane) {
+        const int b = plane / p.C, c = plane - b * p.C;
+        const float* base = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+#pragma unroll
+        for (int it = 0; it < NRP; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            if (item < hh * (w >> 2)) {
+                int f, q;
+                rowpair_item(item, w >> 2, f, q);
+                rxa[it] = *reinterpret_cast<const float4*>(base + (2 * f) * w + q * 4);
+                rxb[it] = *reinterpret_cast<const float4*>(base + (2 * f + 1) * w + q * 4);
+            }
+        }
+    };
+    if constexpr (SEQ > 1) prefetch_spec(blockIdx.x * SEQ);
+#pragma unroll 1
+    for (int sq = 0; sq < SEQ; ++sq) {
+    const int plane0 = (blockIdx.x * SEQ + sq) * ppw;
     // 1. load the Re / Im planes: P[pl][u][k]
+    if constexpr (SEQ > 1) {
+#pragma unroll
+        for (int it = 0; it < NSP; ++it) {
+            const int i4 = tid + it * LAMA_NTHREADS;
+            if (i4 < per_plane / 4) {
+                float2* d = P + i4 * 4;
+                d[0] = make_float2(sre[it].x, sim[it].x);
+                d[1] = make_float2(sre[it].y, sim[it].y);
+                d[2] = make_float2(sre[it].z, sim[it].z);
+                d[3] = make_float2(sre[it].w, sim[it].w);
+            }
+        }
+        if (p.x) prefetch_resid(plane0);
+        if (sq + 1 < SEQ) prefetch_spec(plane0 + 1);
+    } else {
     for (int item = tid; item < np * per_plane; item += LAMA_NTHREADS) {
         int pl = item / per_plane, i = item - pl * per_plane;
         int plane = plane0 + pl;
@@ -279,7 +406,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
         const float* src = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
         P[pl * per_plane + i] = make_float2(src[0], src[per_plane]);
     }
+    }
     __syncthreads();
+    FFT_STAMP(1);
     // 2. Hermitian-symmetrise columns 0 and w/2 along h and pack them into column 0:
     //    G = D_h + i E_h,  D_h[u] = (D[u] + conj(D[-u]))/2  (so that ifft_h(G) = Re z0 + i Re z_{w/2})
     {
@@ -298,8 +427,10 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
         if (act) P[(pl * h + u) * wf] = g;
     }
     __syncthreads();
+    FFT_STAMP(2);
     // 3. inverse column FFTs (length h) over columns 0..w/2-1
     float2* E1 = fft_lds<true>(P, Q, twh, h, np * wh, wf, 1, wh, per_plane);
+    FFT_STAMP(3);
     float2* Z = (E1 == P) ? Q : P;  // row-pair buffer [pl][hh][RSW]
     // 4. build the Hermitian-extended row pairs: W[k] = Za[k] + i Zb[k], W[w-k] = conj(Za[k]) + i conj(Zb[k])
     for (int item = tid; item < np * hh * wh; item += LAMA_NTHREADS) {
@@ -318,11 +449,36 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
         }
     }
     __syncthreads();
+    FFT_STAMP(4);
     // 5. inverse row FFTs (length w)
     float2* O = E1;
     float2* E2 = fft_lds<true>(Z, O, tww, w, np * hh, 1, RSW, np * hh, 0);
+    FFT_STAMP(5);
     // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
-    {
+    if constexpr (SEQ > 1) {
+        const int b = plane0 / p.C, c = plane0 - b * p.C;
+        float* ybase = p.y + (long long)b * p.y_bstride + (long long)c * h * w;
+#pragma unroll
+        for (int it = 0; it < NRP; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            if (item < hh * (w >> 2)) {
+                int f, q;
+                rowpair_item(item, w >> 2, f, q);
+                const float2* s = E2 + f * RSW + q * 4;
+                float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+                float4 ra = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
+                float4 rb = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
+                if (p.x) {
+                    ra.x += rxa[it].x; ra.y += rxa[it].y; ra.z += rxa[it].z; ra.w += rxa[it].w;
+                    rb.x += rxb[it].x; rb.y += rxb[it].y; rb.z += rxb[it].z; rb.w += rxb[it].w;
+                }
+                float* d = ybase + (2 * f) * w + q * 4;
+                *reinterpret_cast<float4*>(d) = ra;
+                *reinterpret_cast<float4*>(d + w) = rb;
+            }
+        }
+        if (sq + 1 < SEQ) __syncthreads();   // the next plane's spectrum overwrites the buffers
+    } else {
         const int wq = w >> 2;
         const int pp = hh * wq;
         for (int item = tid; item < np * pp; item += LAMA_NTHREADS) {
@@ -347,7 +503,10 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
             *reinterpret_cast<float4*>(d + w) = rb;
         }
     }
+    }   // planes of this workgroup
+    FFT_STAMP(6);
 }
+#undef FFT_STAMP
 
 // ------------------------------------------------------------------------------------------------
 // generic path: separable direct DFT through a float2 workspace ws[plane][h][wf]
@@ -630,6 +789,22 @@ size_t fft_lds_bytes(int h, int w, int ppw) {
     return ((size_t)w + h + 2 * buf) * sizeof(float2);
 }
 
+// planes one workgroup of the sized one-plane kernels walks sequentially (request of plane s + 1 under the transform of
+// plane s); LAMA_FFT_SEQ overrides it (1 = one plane per workgroup; A/B runs of the profiling tools and the tests)
+int fft_seq(int nplanes) {
+    const char* e = getenv("LAMA_FFT_SEQ");
+    const int want = e ? atoi(e) : 1;
+    if (want >= 3 && nplanes % 3 == 0) return 3;
+    if (want >= 2 && nplanes % 2 == 0) return 2;
+    return 1;
+}
+
+// profiling tools only: LAMA_FFT_TRACE = device address of (workgroups * 16) int64 -> per-workgroup phase timeline of the 64 x 64 kernels
+long long* fft_trace_buf() {
+    static const unsigned long long tr = [] { const char* e = getenv("LAMA_FFT_TRACE"); return e ? strtoull(e, nullptr, 0) : 0ull; }();
+    return reinterpret_cast<long long*>(tr);
+}
+
 bool fft_args_ok(const lama_tensor* real, const lama_tensor* spec, int batch) {
     if (!real || !spec || !real->ptr || !spec->ptr || batch <= 0) return false;
     if (real->C <= 0 || real->H <= 0 || real->W <= 0) return false;
@@ -665,7 +840,16 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
         const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
         const bool even = p.nplanes % p.ppw == 0;
-        if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
+        const int seq = (p.ppw == 1 && ((p.h == 64 && p.w == 64) || (p.h == 128 && p.w == 128)) &&
+                         (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0) ? fft_seq(p.nplanes) : 1;
+        const dim3 gseq(p.nplanes / seq);
+        p.trace = fft_trace_buf();
+        if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
+        else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
+        else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
+        else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
+        else if (seq == 3 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 3>), gseq, blk, lds, st, p);
+        else if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
         else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((rfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
         else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
         else hipLaunchKernelGGL((rfft2_lds_kernel<0, 0, 0>), grid, blk, lds, st, p);
@@ -720,7 +904,16 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
         const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
         const bool even = p.nplanes % p.ppw == 0;
-        if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
+        const int seq = (p.ppw == 1 && ((p.h == 64 && p.w == 64) || (p.h == 128 && p.w == 128)) &&
+                         (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0) ? fft_seq(p.nplanes) : 1;
+        const dim3 gseq(p.nplanes / seq);
+        p.trace = fft_trace_buf();
+        if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
+        else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
+        else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
+        else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
+        else if (seq == 3 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 3>), gseq, blk, lds, st, p);
+        else if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
         else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((irfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
         else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
         else hipLaunchKernelGGL((irfft2_lds_kernel<0, 0, 0>), grid, blk, lds, st, p);

@@ -259,6 +259,11 @@ static inline hipemu_u32x4 hipemu_buf_load_b128(lama_buf_t r, unsigned voff, uns
     if (o + 16 <= r.n) memcpy(&v, r.p + o, 16);
     return v;
 }
+static inline void hipemu_buf_store_b32(lama_buf_t r, unsigned v, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    if (o + 4 <= r.n) memcpy(const_cast<char*>(r.p) + o, &v, 4);
+}
+#define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) hipemu_buf_store_b32(rsrc, val, voff, soff)
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) hipemu_buf_load_b128(rsrc, voff, soff)

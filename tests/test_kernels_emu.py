@@ -49,6 +49,14 @@ CONV_CASES = [
     dict(cin=32, cout=96, k=3, stride=1, pad=1, H=5, W=6, act=0, bias=False, resid=False, scale=False),    # one chunk, narrow image
     dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),    # flat 1x1, two chunks
     dict(cin=192, cout=200, k=1, stride=1, pad=0, H=12, W=11, act=2, bias=True, resid=False, scale=False),  # odd chunk count
+    # full-M 1x1 workgroups: 384 rows = 12 M-waves, 192 rows = 6 M-waves x 2 K-groups (K-group exchange + one residual set)
+    dict(cin=128, cout=384, k=1, stride=1, pad=0, H=5, W=33, act=1, bias=True, resid=True, scale=True),
+    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=9, W=16, act=1, bias=True, resid=True, scale=True),
+    dict(cin=64, cout=370, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False),   # ragged rows, one chunk
+    # weights-stationary persistent GEMM (conv_ws_dev.inc): K = 192 / 384, rows in groups of 96, ragged last tile, 1 / 2 / 4 row groups
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True),
+    dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False),
+    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True),      # rows past M in the last fragment
 ]
 
 
@@ -164,6 +172,29 @@ def test_rfft2_irfft2_emulated(hw):
     y2 = torch.zeros(B, Cn, h, w)
     lib.irfft2(L.view(spec2), None, L.view(y2), B, ws)
     assert torch.allclose(y2, ref2 - resid, atol=tol, rtol=1e-4)
+
+
+@pytest.mark.parametrize('hw_seq', [(64, 1), (64, 2), (64, 3), (128, 3)], ids=lambda s: f'{s[0]}x{s[0]}seq{s[1]}')
+def test_fft_sequential_planes_emulated(hw_seq, monkeypatch):
+    """Sized one-plane kernels walking SEQ consecutive planes per workgroup with the next plane prefetched (LAMA_FFT_SEQ)."""
+    lib = emu_lib()
+    n, seq = hw_seq
+    monkeypatch.setenv('LAMA_FFT_SEQ', str(seq))
+    g = torch.Generator().manual_seed(n + seq)
+    B, Cn = 2, 3
+    wide = torch.randn(B, Cn + 1, n, n, generator=g)
+    x = wide[:, 1:]
+    spec = torch.zeros(B, 2 * Cn, n, n // 2 + 1)
+    lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, None)
+    ref = _spec_ref(x)
+    assert torch.allclose(spec, ref, atol=3e-5, rtol=1e-4), float((spec - ref).abs().max())
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, n, n // 2 + 1, generator=g))
+    resid = torch.randn(B, Cn, n, n, generator=g)
+    for r in (resid, None):
+        y = torch.zeros(B, Cn, n, n)
+        lib.irfft2(L.view(spec2), None if r is None else L.view(r), L.view(y), B, None)
+        ref2 = _inv_ref(spec2, n, n) + (0 if r is None else r)
+        assert torch.allclose(y, ref2, atol=3e-5, rtol=1e-4), float((y - ref2).abs().max())
 
 
 def test_fourier_unit_emulated():

@@ -51,7 +51,8 @@ def test_conv2d(lib, case, prec):
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 @pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
-                                   (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64)])
+                                   (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64),
+                                   (4, 384, 192, 1, 64, 64), (6, 384, 384, 1, 64, 33)])   # the last two: full-M 1x1 workgroups
 def test_conv2d_big_tiles(lib, shape, prec):
     """Full-size channel counts (BM=128 tiles, many K chunks) against torch fp32 on the GPU's host."""
     B, cin, cout, k, H, W = shape
@@ -132,6 +133,29 @@ def test_rfft2_irfft2(lib, hw):
     lib.irfft2(L.view(s2d), L.view(rd), L.view(y), B, ws, stream=st)
     ref2 = resid + _inv_ref(spec2, h, w)
     assert torch.allclose(y.cpu(), ref2, atol=tol, rtol=1e-4), float((y.cpu() - ref2).abs().max())
+
+
+@pytest.mark.parametrize('n_seq', [(64, 1), (64, 2), (64, 3), (128, 2), (128, 3)], ids=lambda s: f'{s[0]}seq{s[1]}')
+def test_fft_sequential_planes(lib, n_seq, monkeypatch):
+    """Sized one-plane FFT kernels walking LAMA_FFT_SEQ consecutive planes per workgroup (next plane prefetched)."""
+    n, seq = n_seq
+    monkeypatch.setenv('LAMA_FFT_SEQ', str(seq))
+    g = torch.Generator().manual_seed(n + seq)
+    B, Cn = 2, 12
+    x = torch.randn(B, Cn, n, n, generator=g)
+    xd = x.to(DEV)
+    spec = torch.zeros(B, 2 * Cn, n, n // 2 + 1, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rfft2(L.view(xd), L.view(spec), B, None, stream=st)
+    ref = _spec_ref(x)
+    assert torch.allclose(spec.cpu(), ref, atol=3e-5, rtol=1e-4), float((spec.cpu() - ref).abs().max())
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, n, n // 2 + 1, generator=g))
+    resid = torch.randn(B, Cn, n, n, generator=g)
+    y = torch.zeros(B, Cn, n, n, device=DEV)
+    s2d, rd = spec2.to(DEV), resid.to(DEV)
+    lib.irfft2(L.view(s2d), L.view(rd), L.view(y), B, None, stream=st)
+    ref2 = resid + _inv_ref(spec2, n, n)
+    assert torch.allclose(y.cpu(), ref2, atol=3e-5, rtol=1e-4), float((y.cpu() - ref2).abs().max())
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)

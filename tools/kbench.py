@@ -28,6 +28,8 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
+    only_fu = len(sys.argv) > 2 and sys.argv[2] == 'fu'      # spectral branch only: the 1x1 GEMMs and the FFT kernels
+    out_tag = sys.argv[3] if len(sys.argv) > 3 else tag
     prec = L.PREC_NAMES[tag]
     lib = L.get_lib()
     dev = 'cuda'
@@ -40,6 +42,8 @@ def main():
         return torch.randn(*s, generator=g).to(dev)
 
     def conv_case(name, cin, cout, k, H, W, stride=1, tr=False, x2c=0, flops=None, bytes_=None):
+        if only_fu and k != 1:
+            return
         x = rnd(B, cin, H, W)
         wt = rnd(cin, cout, k, k) if tr else rnd(cout, cin, k, k)
         stride = 2 if tr else stride
@@ -90,7 +94,7 @@ def main():
         print(k, res[k], flush=True)
 
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(ROOT, 'gpurun_out', f'kbench_{tag}.json'), 'w') as f:
+    with open(os.path.join(ROOT, 'gpurun_out', f'kbench_{out_tag}.json'), 'w') as f:
         json.dump(res, f, indent=1)
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-workgroup timeline of the weights-in-registers kernels (LAMA_CW_TRACE).  usage: wr_trace.py [convA|fuconv]"""
+"""Per-workgroup timeline of the weights-in-registers kernels (LAMA_CW_TRACE).  usage: wr_trace.py [convA|fuconv|conv1]"""
 import os
 import sys
 
@@ -17,7 +17,7 @@ prec = L.PREC_F16X3
 st = torch.cuda.current_stream().cuda_stream
 B = 8
 g = torch.Generator().manual_seed(0)
-cin, cout, k, H, W = (512, 128, 3, 64, 64) if name == 'convA' else (384, 384, 1, 64, 33)
+cin, cout, k, H, W = {'convA': (512, 128, 3, 64, 64), 'conv1': (384, 192, 1, 64, 64)}.get(name, (384, 384, 1, 64, 33))
 x = torch.randn(B, cin, H, W, generator=g).cuda()
 wt = torch.randn(cout, cin, k, k, generator=g).cuda()
 wp = lib.pack_conv_weight(wt, None, stride=1, transposed=False, precision=prec)
