@@ -1,10 +1,8 @@
 #!/bin/bash
-# profiling session: per-workgroup timelines of the spectral-branch kernels
 OUT=gpurun_out/${1:-trace}
 mkdir -p $OUT
-for cfg in "0 fuconv" "1 fuconv" "0 conv1" "1 conv1"; do
-  set -- $cfg
-  echo "== wr_trace LAMA_CW_1X1=$1 $2"
-  LAMA_CW_1X1=$1 timeout 120 python tools/wr_trace.py $2 2>&1 | grep -v amdgpu.ids
-done | tee $OUT/wr_trace.txt
-for k in rfft irfft; do timeout 120 python tools/fft_trace.py $k 2>&1 | grep -v amdgpu.ids; done | tee $OUT/fft_trace.txt
+for a in 0 3; do echo "== LAMA_GW_ABLATE=$a"; LAMA_GW_ABLATE=$a timeout 120 python tools/gw_trace.py fuconv 6 2>&1 | grep -v amdgpu.ids | tail -9; done | tee $OUT/gw_abl.txt
+timeout 120 python tools/gw_trace.py conv1 6 2>&1 | grep -v amdgpu.ids | tail -9 | tee -a $OUT/gw_abl.txt
+timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-f32-leg 2>&1 | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step']); print({k:v for k,v in list(d['kernels_us'].items())[:4]})" | tee -a $OUT/gw_abl.txt
