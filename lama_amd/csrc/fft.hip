@@ -509,6 +509,244 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
 #undef FFT_STAMP
 
 // ------------------------------------------------------------------------------------------------
+// 64 x 64 planes, ONE LDS buffer per workgroup (17.5 KB instead of 34 KB): every phase reads its operands into registers,
+// meets at a barrier and writes its results back into the same buffer (Stockham passes, the pair untangle and the layout
+// change between row pairs [32][65] and spectrum [64][33] alike).  The two-buffer kernels above fit four workgroups per CU,
+// so the 1536 planes of the bottleneck run as 1.5 rounds of latency-bound phases; with one buffer seven fit (registers) and
+// every plane of the launch is resident at once.
+// ------------------------------------------------------------------------------------------------
+#define IP_N 64
+#define IP_WF 33
+#define IP_RSW 65
+#define IP_BUF (IP_N * IP_WF)          // float2 elements: 64 x 33 >= 32 x 65
+
+// one radix-8 Stockham pass over 32 FFTs of length 64, in place: thread = (FFT f = tid % 32, butterfly j = tid / 32)
+template <bool INV>
+__device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, int estride, int fstride) {
+    const int tid = threadIdx.x;
+    const int f = tid & 31, j = tid >> 5;        // j in 0..7 (N / R = 8 butterflies per FFT)
+    const int k = j & (Ns - 1);
+    float2* s = buf + f * fstride;
+    float2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = s[(j + r * 8) * estride];
+    if (Ns > 1) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw[r * k * (IP_N / (Ns * 8))]);
+    }
+    dft8<INV>(v);
+    __syncthreads();
+    const int j0 = (j - k) * 8 + k;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s[(j0 + r * Ns) * estride] = v[r];
+    __syncthreads();
+}
+
+template <bool TR = false>
+__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
+    constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
+    float2* tww = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tww + w;                       // h == w: one twiddle table
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x;
+    const int b = plane / p.C, c = plane - b * p.C;
+    // 1. row pairs straight from HBM (requested before the twiddles are computed): P[f][n] = (x[2f][n], x[2f+1][n])
+    float4 ra[2], rb[2];
+    const float* xin = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int f, q;
+        rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
+        ra[it] = *reinterpret_cast<const float4*>(xin + (2 * f) * w + q * 4);
+        rb[it] = *reinterpret_cast<const float4*>(xin + (2 * f + 1) * w + q * 4);
+    }
+    fft_init_twiddles<false>(tww, w);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        int f, q;
+        rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
+        float2* d = P + f * RSW + q * 4;
+        d[0] = make_float2(ra[it].x, rb[it].x);
+        d[1] = make_float2(ra[it].y, rb[it].y);
+        d[2] = make_float2(ra[it].z, rb[it].z);
+        d[3] = make_float2(ra[it].w, rb[it].w);
+    }
+    __syncthreads();
+    // 2. row FFTs of the 32 packed row pairs (FFT f = row pair, element stride 1, FFT stride RSW)
+    ip_pass<false>(P, tww, 1, 1, RSW);
+    ip_pass<false>(P, tww, 8, 1, RSW);
+    // 3. untangle the pairs into the half spectra of the two rows, row-pair layout [32][65] -> spectrum layout [64][33]
+    {
+        float2 oa[4], ob[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item & 31, k = item >> 5;          // k in 0..31
+            const float2* z = P + f * RSW;
+            if (k == 0) {
+                const float2 z0 = z[0], zn = z[wh];
+                oa[it] = make_float2(z0.x, zn.x);
+                ob[it] = make_float2(z0.y, zn.y);
+            } else {
+                const float2 zk = z[k], zm = z[w - k];
+                oa[it] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                ob[it] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item & 31, k = item >> 5;
+            P[(2 * f) * wf + k] = oa[it];
+            P[(2 * f + 1) * wf + k] = ob[it];
+        }
+        __syncthreads();
+    }
+    // 4. column FFTs over columns 0..31 (column 0 packs DC + Nyquist): FFT f = column, element stride wf, FFT stride 1
+    ip_pass<false>(P, tww, 1, wf, 1);
+    ip_pass<false>(P, tww, 8, wf, 1);
+    // 5 + 6. float4 stores of the Re / Im planes; DC (col 0) and Nyquist (col 32) untangled from the packed column 0 on the fly
+    {
+        const int per_plane = h * wf;
+        float* dre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
+            float re[4], im[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i4 * 4 + e;
+                const int k = i / wf, col = i - k * wf;
+                float2 v = P[col == wh ? k * wf : i];
+                if (col == 0 || col == wh) {
+                    const float2 cc = P[k * wf], cm = P[((h - k) & (h - 1)) * wf];
+                    v = col == 0 ? make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y)) : make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
+                }
+                re[e] = v.x * p.scale;
+                im[e] = v.y * p.scale;
+            }
+            *reinterpret_cast<float4*>(dre + i4 * 4) = make_float4(re[0], re[1], re[2], re[3]);
+            *reinterpret_cast<float4*>(dre + per_plane + i4 * 4) = make_float4(im[0], im[1], im[2], im[3]);
+        }
+    }
+}
+
+template <bool TR = false>
+__global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p) {
+    constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
+    constexpr int per_plane = h * wf;
+    float2* tww = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tww + w;
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x;
+    const int b = plane / p.C, c = plane - b * p.C;
+    // 1. the Re / Im planes (float4 loads, requested before the twiddles are computed) and the residual rows
+    const float* sbase = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    float4 sre[3], sim[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int i4 = tid + it * LAMA_NTHREADS;
+        if (i4 < per_plane / 4) {
+            sre[it] = *reinterpret_cast<const float4*>(sbase + i4 * 4);
+            sim[it] = *reinterpret_cast<const float4*>(sbase + per_plane + i4 * 4);
+        }
+    }
+    float4 rxa[2], rxb[2];
+    if (p.x) {
+        const float* rbase = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int f, q;
+            rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
+            rxa[it] = *reinterpret_cast<const float4*>(rbase + (2 * f) * w + q * 4);
+            rxb[it] = *reinterpret_cast<const float4*>(rbase + (2 * f + 1) * w + q * 4);
+        }
+    }
+    fft_init_twiddles<true>(tww, w);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int i4 = tid + it * LAMA_NTHREADS;
+        if (i4 < per_plane / 4) {
+            float2* d = P + i4 * 4;
+            d[0] = make_float2(sre[it].x, sim[it].x);
+            d[1] = make_float2(sre[it].y, sim[it].y);
+            d[2] = make_float2(sre[it].z, sim[it].z);
+            d[3] = make_float2(sre[it].w, sim[it].w);
+        }
+    }
+    __syncthreads();
+    // 2. Hermitian-symmetrise columns 0 and w/2 along h and pack them into column 0 (see irfft2_lds_kernel)
+    {
+        float2 g = make_float2(0.f, 0.f);
+        const bool act = tid < h;
+        const int u = tid;
+        if (act) {
+            const float2* r0 = P + u * wf;
+            const float2* r1 = P + ((h - u) & (h - 1)) * wf;
+            const float2 d = r0[0], dm = r1[0], e = r0[wh], em = r1[wh];
+            const float2 dh = make_float2(0.5f * (d.x + dm.x), 0.5f * (d.y - dm.y));
+            const float2 eh = make_float2(0.5f * (e.x + em.x), 0.5f * (e.y - em.y));
+            g = make_float2(dh.x - eh.y, dh.y + eh.x);
+        }
+        __syncthreads();
+        if (act) P[u * wf] = g;
+        __syncthreads();
+    }
+    // 3. inverse column FFTs over columns 0..31
+    ip_pass<true>(P, tww, 1, wf, 1);
+    ip_pass<true>(P, tww, 8, wf, 1);
+    // 4. Hermitian-extended row pairs, spectrum layout [64][33] -> row-pair layout [32][65]
+    {
+        float2 o0[4], o1[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item & 31, k = item >> 5;
+            const float2 za = P[(2 * f) * wf + k], zb = P[(2 * f + 1) * wf + k];
+            if (k == 0) {
+                o0[it] = make_float2(za.x, zb.x);
+                o1[it] = make_float2(za.y, zb.y);
+            } else {
+                o0[it] = make_float2(za.x - zb.y, za.y + zb.x);
+                o1[it] = make_float2(za.x + zb.y, zb.x - za.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item & 31, k = item >> 5;
+            float2* z = P + f * RSW;
+            z[k] = o0[it];
+            z[k == 0 ? wh : w - k] = o1[it];
+        }
+        __syncthreads();
+    }
+    // 5. inverse row FFTs
+    ip_pass<true>(P, tww, 1, 1, RSW);
+    ip_pass<true>(P, tww, 8, 1, RSW);
+    // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
+    {
+        float* ybase = p.y + (long long)b * p.y_bstride + (long long)c * h * w;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            int f, q;
+            rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
+            const float2* s = P + f * RSW + q * 4;
+            const float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+            float4 oa = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
+            float4 ob = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
+            if (p.x) {
+                oa.x += rxa[it].x; oa.y += rxa[it].y; oa.z += rxa[it].z; oa.w += rxa[it].w;
+                ob.x += rxb[it].x; ob.y += rxb[it].y; ob.z += rxb[it].z; ob.w += rxb[it].w;
+            }
+            float* d = ybase + (2 * f) * w + q * 4;
+            *reinterpret_cast<float4*>(d) = oa;
+            *reinterpret_cast<float4*>(d + w) = ob;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic path: separable direct DFT through a float2 workspace ws[plane][h][wf]
 // ------------------------------------------------------------------------------------------------
 #define DFT_ROWS_PER_WG 8
@@ -805,6 +1043,13 @@ long long* fft_trace_buf() {
     return reinterpret_cast<long long*>(tr);
 }
 
+// one-buffer 64 x 64 kernels (rfft2_ip64_kernel / irfft2_ip64_kernel); LAMA_FFT_INPLACE=0 keeps the two-buffer kernels (A/B
+// runs of the profiling tools and the tests)
+bool fft_inplace() {
+    const char* e = getenv("LAMA_FFT_INPLACE");
+    return !(e && atoi(e) == 0);
+}
+
 bool fft_args_ok(const lama_tensor* real, const lama_tensor* spec, int batch) {
     if (!real || !spec || !real->ptr || !spec->ptr || batch <= 0) return false;
     if (real->C <= 0 || real->H <= 0 || real->W <= 0) return false;
@@ -844,7 +1089,9 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
                          (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0) ? fft_seq(p.nplanes) : 1;
         const dim3 gseq(p.nplanes / seq);
         p.trace = fft_trace_buf();
-        if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
+        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
+            hipLaunchKernelGGL((rfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
+        else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
         else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
         else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
@@ -908,7 +1155,9 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
                          (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0) ? fft_seq(p.nplanes) : 1;
         const dim3 gseq(p.nplanes / seq);
         p.trace = fft_trace_buf();
-        if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
+        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
+            hipLaunchKernelGGL((irfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
+        else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
         else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
         else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
