@@ -66,6 +66,18 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #define LAMA_CLOCK() ((long long)wall_clock64())   // 100 MHz constant counter (timeline traces of the profiling tools)
 #endif
 
+// LDS hand-off between the lanes of ONE wave (wave-private LDS regions, no workgroup barrier): the LDS pipe executes a wave's
+// instructions in order, so only the compiler has to be kept from moving accesses across this point.  (tests/hipemu maps it
+// to its per-wave barrier.)
+#ifndef LAMA_WAVE_SYNC
+#define LAMA_WAVE_SYNC()                                              \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
+    } while (0)
+#endif
+
 // make a per-lane integer opaque to the optimiser at this point of the program (pins the loads that depend on it behind the
 // code above: epilogue loads must not be hoisted over the main loop, where their registers are needed)
 #ifndef LAMA_OPAQUE

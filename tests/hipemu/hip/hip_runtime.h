@@ -268,6 +268,7 @@ static inline void hipemu_buf_store_b32(lama_buf_t r, unsigned v, unsigned voff,
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) hipemu_buf_load_b128(rsrc, voff, soff)
 #define LAMA_WAVE_UNIFORM(x) (x)
+#define LAMA_WAVE_SYNC() hipemu::wave_barrier()
 #define LAMA_CLOCK() 0ll
 
 // math helpers that exist in HIP device code

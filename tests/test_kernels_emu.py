@@ -57,6 +57,9 @@ CONV_CASES = [
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True),
     dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False),
     dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True),      # rows past M in the last fragment
+    # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
+    dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True),
+    dict(cin=3, cout=40, k=7, stride=1, pad=3, H=6, W=20, act=0, bias=False, resid=False, scale=False),
 ]
 
 
