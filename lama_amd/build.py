@@ -18,7 +18,7 @@ CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'liblama_hip.so')
 SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'fft.hip', 'elementwise.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'),
+HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'),
            os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
                '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]

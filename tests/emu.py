@@ -7,6 +7,7 @@ import sys
 os.environ.setdefault('LAMA_CW_1X1', '2')
 os.environ.setdefault('LAMA_GEMM_WS', '2')
 os.environ.setdefault('LAMA_STEM_WS', '2')
+os.environ.setdefault('LAMA_HEAD_WS', '2')
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'hipemu'))

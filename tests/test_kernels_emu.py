@@ -60,6 +60,9 @@ CONV_CASES = [
     # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
     dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True),
     dict(cin=3, cout=40, k=7, stride=1, pad=3, H=6, W=20, act=0, bias=False, resid=False, scale=False),
+    # head kernel (conv_head_dev.inc): 7x7, 64 input channels, <= 4 output channels; two 26-column segments (ragged), rows not a multiple of 7
+    dict(cin=64, cout=3, k=7, stride=1, pad=3, H=10, W=40, act=2, bias=True, resid=False, scale=False),
+    dict(cin=64, cout=4, k=7, stride=1, pad=3, H=16, W=26, act=0, bias=False, resid=False, scale=True),
 ]
 
 
