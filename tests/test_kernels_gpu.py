@@ -52,7 +52,10 @@ def test_conv2d(lib, case, prec):
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 @pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
                                    (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64),
-                                   (4, 384, 192, 1, 64, 64), (6, 384, 384, 1, 64, 33)])   # the last two: full-M 1x1 workgroups
+                                   (4, 384, 192, 1, 64, 64), (6, 384, 384, 1, 64, 33),   # persistent pointwise GEMM (conv_ws_dev.inc), K = 384
+                                   (8, 192, 192, 1, 64, 64),                             # ... K = 192
+                                   (2, 4, 64, 7, 512, 256),                              # stem kernel (conv_stem_dev.inc)
+                                   (2, 64, 3, 7, 512, 416)])                             # head kernel (conv_head_dev.inc)
 def test_conv2d_big_tiles(lib, shape, prec):
     """Full-size channel counts (BM=128 tiles, many K chunks) against torch fp32 on the GPU's host."""
     B, cin, cout, k, H, W = shape
