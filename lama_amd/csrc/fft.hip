@@ -747,6 +747,242 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same one-buffer construction for N x N planes with more than one item per thread and phase (N = 128: the bottleneck planes
+// of 1024 x 1024 inputs; passes radix 8, 8, 2).  LDS per workgroup: 67.6 KB instead of 133 KB -> two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+template <int R, int N, int NF, bool INV>
+__device__ __forceinline__ void ipn_pass(float2* buf, const float2* tw, int Ns, int estride, int fstride) {
+    constexpr int NB = N / R, ITEMS = NF * NB, IT = ITEMS / LAMA_NTHREADS;
+    static_assert(ITEMS % LAMA_NTHREADS == 0, "items per pass must fill the workgroup evenly");
+    const int tid = threadIdx.x;
+    float2 v[IT][R];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int item = tid + it * LAMA_NTHREADS;
+        const int f = item % NF, j = item / NF;
+        const int k = j & (Ns - 1);
+        const float2* s = buf + f * fstride;
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[it][r] = s[(j + r * NB) * estride];
+        if (Ns > 1) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], tw[r * k * (N / (Ns * R))]);
+        }
+        if constexpr (R == 8) dft8<INV>(v[it]);
+        else dft2<INV>(v[it][0], v[it][1]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int item = tid + it * LAMA_NTHREADS;
+        const int f = item % NF, j = item / NF;
+        const int k = j & (Ns - 1);
+        float2* s = buf + f * fstride;
+        const int j0 = (j - k) * R + k;
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[(j0 + r * Ns) * estride] = v[it][r];
+    }
+    __syncthreads();
+}
+
+template <int N, bool INV>
+__device__ __forceinline__ void ipn_fft(float2* buf, const float2* tw, int estride, int fstride) {
+    static_assert(N == 128, "pass list");
+    ipn_pass<8, N, N / 2, INV>(buf, tw, 1, estride, fstride);
+    ipn_pass<8, N, N / 2, INV>(buf, tw, 8, estride, fstride);
+    ipn_pass<2, N, N / 2, INV>(buf, tw, 64, estride, fstride);
+}
+
+template <int N>
+__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
+    constexpr int h = N, w = N, wf = N / 2 + 1, hh = N / 2, wh = N / 2, RSW = N + 1;
+    constexpr int NLD = hh * (w / 4) / LAMA_NTHREADS;          // row-pair float4 items per thread
+    constexpr int NUT = hh * wh / LAMA_NTHREADS;               // untangle items per thread
+    float2* tww = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tww + w;                                       // h == w: one twiddle table
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x;
+    const int b = plane / p.C, c = plane - b * p.C;
+    const float* xin = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+    {   // 1. row pairs: P[f][n] = (x[2f][n], x[2f+1][n]), in two halves (registers)
+        float4 ra[NLD / 2], rb[NLD / 2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int it = 0; it < NLD / 2; ++it) {
+                int f, q;
+                rowpair_item(tid + (half * (NLD / 2) + it) * LAMA_NTHREADS, w >> 2, f, q);
+                ra[it] = *reinterpret_cast<const float4*>(xin + (2 * f) * w + q * 4);
+                rb[it] = *reinterpret_cast<const float4*>(xin + (2 * f + 1) * w + q * 4);
+            }
+            if (half == 0) fft_init_twiddles<false>(tww, w);
+#pragma unroll
+            for (int it = 0; it < NLD / 2; ++it) {
+                int f, q;
+                rowpair_item(tid + (half * (NLD / 2) + it) * LAMA_NTHREADS, w >> 2, f, q);
+                float2* d = P + f * RSW + q * 4;
+                d[0] = make_float2(ra[it].x, rb[it].x);
+                d[1] = make_float2(ra[it].y, rb[it].y);
+                d[2] = make_float2(ra[it].z, rb[it].z);
+                d[3] = make_float2(ra[it].w, rb[it].w);
+            }
+        }
+    }
+    __syncthreads();
+    // 2. row FFTs of the packed row pairs
+    ipn_fft<N, false>(P, tww, 1, RSW);
+    // 3. untangle: row-pair layout [N/2][N+1] -> spectrum layout [N][N/2+1], through registers
+    {
+        float2 oa[NUT], ob[NUT];
+#pragma unroll
+        for (int it = 0; it < NUT; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item % hh, k = item / hh;
+            const float2* z = P + f * RSW;
+            if (k == 0) {
+                const float2 z0 = z[0], zn = z[wh];
+                oa[it] = make_float2(z0.x, zn.x);
+                ob[it] = make_float2(z0.y, zn.y);
+            } else {
+                const float2 zk = z[k], zm = z[w - k];
+                oa[it] = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                ob[it] = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NUT; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item % hh, k = item / hh;
+            P[(2 * f) * wf + k] = oa[it];
+            P[(2 * f + 1) * wf + k] = ob[it];
+        }
+        __syncthreads();
+    }
+    // 4. column FFTs over columns 0..N/2-1 (column 0 packs DC + Nyquist)
+    ipn_fft<N, false>(P, tww, wf, 1);
+    // 5 + 6. float4 stores of the Re / Im planes; DC and Nyquist untangled from the packed column 0 on the fly
+    {
+        constexpr int per_plane = h * wf;
+        float* dre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
+            float re[4], im[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i4 * 4 + e;
+                const int k = i / wf, col = i - k * wf;
+                float2 v = P[col == wh ? k * wf : i];
+                if (col == 0 || col == wh) {
+                    const float2 cc = P[k * wf], cm = P[((h - k) & (h - 1)) * wf];
+                    v = col == 0 ? make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y)) : make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
+                }
+                re[e] = v.x * p.scale;
+                im[e] = v.y * p.scale;
+            }
+            *reinterpret_cast<float4*>(dre + i4 * 4) = make_float4(re[0], re[1], re[2], re[3]);
+            *reinterpret_cast<float4*>(dre + per_plane + i4 * 4) = make_float4(im[0], im[1], im[2], im[3]);
+        }
+    }
+}
+
+template <int N>
+__global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) {
+    constexpr int h = N, w = N, wf = N / 2 + 1, hh = N / 2, wh = N / 2, RSW = N + 1;
+    constexpr int per_plane = h * wf;
+    constexpr int NUT = hh * wh / LAMA_NTHREADS;
+    constexpr int NST = hh * (w / 4) / LAMA_NTHREADS;
+    float2* tww = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tww + w;
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x;
+    const int b = plane / p.C, c = plane - b * p.C;
+    // 1. the Re / Im planes
+    const float* sbase = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    fft_init_twiddles<true>(tww, w);
+    for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
+        const float4 sre = *reinterpret_cast<const float4*>(sbase + i4 * 4);
+        const float4 sim = *reinterpret_cast<const float4*>(sbase + per_plane + i4 * 4);
+        float2* d = P + i4 * 4;
+        d[0] = make_float2(sre.x, sim.x);
+        d[1] = make_float2(sre.y, sim.y);
+        d[2] = make_float2(sre.z, sim.z);
+        d[3] = make_float2(sre.w, sim.w);
+    }
+    __syncthreads();
+    // 2. Hermitian-symmetrise columns 0 and w/2 along h and pack them into column 0 (see irfft2_lds_kernel)
+    {
+        float2 g = make_float2(0.f, 0.f);
+        const bool act = tid < h;
+        const int u = tid;
+        if (act) {
+            const float2* r0 = P + u * wf;
+            const float2* r1 = P + ((h - u) & (h - 1)) * wf;
+            const float2 d = r0[0], dm = r1[0], e = r0[wh], em = r1[wh];
+            const float2 dh = make_float2(0.5f * (d.x + dm.x), 0.5f * (d.y - dm.y));
+            const float2 eh = make_float2(0.5f * (e.x + em.x), 0.5f * (e.y - em.y));
+            g = make_float2(dh.x - eh.y, dh.y + eh.x);
+        }
+        __syncthreads();
+        if (act) P[u * wf] = g;
+        __syncthreads();
+    }
+    // 3. inverse column FFTs over columns 0..N/2-1
+    ipn_fft<N, true>(P, tww, wf, 1);
+    // 4. Hermitian-extended row pairs, spectrum layout -> row-pair layout, through registers
+    {
+        float2 o0[NUT], o1[NUT];
+#pragma unroll
+        for (int it = 0; it < NUT; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item % hh, k = item / hh;
+            const float2 za = P[(2 * f) * wf + k], zb = P[(2 * f + 1) * wf + k];
+            if (k == 0) {
+                o0[it] = make_float2(za.x, zb.x);
+                o1[it] = make_float2(za.y, zb.y);
+            } else {
+                o0[it] = make_float2(za.x - zb.y, za.y + zb.x);
+                o1[it] = make_float2(za.x + zb.y, zb.x - za.y);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NUT; ++it) {
+            const int item = tid + it * LAMA_NTHREADS;
+            const int f = item % hh, k = item / hh;
+            float2* z = P + f * RSW;
+            z[k] = o0[it];
+            z[k == 0 ? wh : w - k] = o1[it];
+        }
+        __syncthreads();
+    }
+    // 5. inverse row FFTs
+    ipn_fft<N, true>(P, tww, 1, RSW);
+    // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
+    {
+        float* ybase = p.y + (long long)b * p.y_bstride + (long long)c * h * w;
+        const float* rbase = p.x ? p.x + (long long)b * p.x_bstride + (long long)c * h * w : nullptr;
+#pragma unroll
+        for (int it = 0; it < NST; ++it) {
+            int f, q;
+            rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
+            const float2* s = P + f * RSW + q * 4;
+            const float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+            float4 oa = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
+            float4 ob = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
+            if (rbase) {
+                const float4 xa = *reinterpret_cast<const float4*>(rbase + (2 * f) * w + q * 4);
+                const float4 xb = *reinterpret_cast<const float4*>(rbase + (2 * f + 1) * w + q * 4);
+                oa.x += xa.x; oa.y += xa.y; oa.z += xa.z; oa.w += xa.w;
+                ob.x += xb.x; ob.y += xb.y; ob.z += xb.z; ob.w += xb.w;
+            }
+            float* d = ybase + (2 * f) * w + q * 4;
+            *reinterpret_cast<float4*>(d) = oa;
+            *reinterpret_cast<float4*>(d + w) = ob;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // generic path: separable direct DFT through a float2 workspace ws[plane][h][wf]
 // ------------------------------------------------------------------------------------------------
 #define DFT_ROWS_PER_WG 8
@@ -1091,6 +1327,8 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
         p.trace = fft_trace_buf();
         if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
             hipLaunchKernelGGL((rfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
+        else if (p.h == 128 && p.w == 128 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
+            hipLaunchKernelGGL((rfft2_ipn_kernel<128>), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), st, p);
         else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
         else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
@@ -1157,6 +1395,8 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
         p.trace = fft_trace_buf();
         if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
             hipLaunchKernelGGL((irfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
+        else if (p.h == 128 && p.w == 128 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
+            hipLaunchKernelGGL((irfft2_ipn_kernel<128>), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), st, p);
         else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
         else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);

@@ -148,7 +148,7 @@ def _inv_ref(spec, h, w):
     return torch.fft.irfftn(torch.complex(s[:, :, 0], s[:, :, 1]), s=(h, w), dim=(-2, -1), norm='ortho')
 
 
-FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32),   # fused LDS path
+FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32), (128, 128),   # fused LDS path (64 / 128 squares: one-buffer kernels)
              (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13),          # generic DFT path
              (256, 32), (16, 512), (256, 256)]                                # two-pass LDS path
 
