@@ -20,7 +20,18 @@ The JSON line also carries
   roofline_ffc  -- the unit BASELINE.json names: FourierUnit forward (rfft2 -> spectral 1x1+BN+ReLU ->
                    irfft2 + residual), algorithmic bytes / time against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (CPU restatement of the reference, same torch-CPU primitives) timed on
-                   the host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                   the host cores on a bounded sample of the same workload (rank 0, N = 1 only), in the
+                   three modes of BASELINE.md section 3: batch-1 loop (bin/predict.py mode; = `value`),
+                   one batched forward, and OMP_NUM_THREADS=1.
+  pytorch_rocm_eager -- BASELINE configs[1]'s comparator: the same generator as PyTorch-ROCm eager ops
+                   (MIOpen convs, rocFFT rfftn / irfftn) on the same GPU, timed in a subprocess outside the
+                   timed region (the oracle's functional restatement moved to cuda; /root/reference does not
+                   exist on the GPU box).
+  value_with_h2d_d2h -- the same step fed from pinned host buffers (fp32 image + mask in, u8 out) over PCIe,
+                   copies on the compute stream (not overlapped).  Never `value`.
+
+`--gpus N` without a torch.distributed environment re-executes itself under torch.distributed.run with N
+ranks (one per GPU, RCCL) and relays rank 0's JSON line.
 """
 import argparse
 import json
@@ -50,15 +61,27 @@ MFMA_F32_PEAK_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0
 
 
-def synthetic_batch(device, seed):
+def synthetic_batch(device, seed, batch=None, res=None):
+    """image uniform [0,1) quantised to u8/255; mask = centred rectangle (25 % of the area) + 3 random strokes."""
+    b, r = batch or BATCH, res or RES
     g = torch.Generator().manual_seed(seed)
-    img = torch.floor(torch.rand(BATCH, 3, RES, RES, generator=g) * 256) / 255.0
-    mask = torch.zeros(BATCH, 1, RES, RES)
-    mask[:, :, RES // 4: 3 * RES // 4, RES // 4: 3 * RES // 4] = 1.0
+    img = torch.floor(torch.rand(b, 3, r, r, generator=g) * 256).clamp_(0, 255) / 255.0
+    mask = torch.zeros(b, 1, r, r)
+    mask[:, :, r // 4: r // 4 + r // 2, r // 4: r // 4 + r // 2] = 1.0
+    gs = torch.Generator().manual_seed(4321 + seed)
+    for bi in range(b):
+        for _ in range(3):
+            y0, x0 = int(torch.randint(0, r, (1,), generator=gs)), int(torch.randint(0, r, (1,), generator=gs))
+            ln = int(torch.randint(max(2, r // 8), max(3, r // 2), (1,), generator=gs))
+            th = max(1, r // 32)
+            if int(torch.randint(0, 2, (1,), generator=gs)):
+                mask[bi, 0, y0:y0 + th, x0:x0 + ln] = 1.0
+            else:
+                mask[bi, 0, y0:y0 + ln, x0:x0 + th] = 1.0
     return img.to(device), mask.to(device)
 
 
-def build_model(device, precision):
+def build_model(device, precision, to_device=True):
     torch.manual_seed(0)
     model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(BIG_LAMA)))
     # random-init weights; give the BatchNorms non-trivial statistics so nothing folds to identity
@@ -69,8 +92,10 @@ def build_model(device, precision):
             m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.2
             m.running_mean.data = torch.randn(m.bias.shape, generator=g) * 0.1
             m.running_var.data = torch.rand(m.bias.shape, generator=g) + 0.5
-    model.freeze().to(device)
-    model.generator.set_precision(precision)
+    model.freeze()
+    if to_device:
+        model.to(device)
+        model.generator.set_precision(precision)
     return model
 
 
@@ -128,24 +153,105 @@ def pmc_traffic(kernel_key, precision):
     return None
 
 
-def cpu_baseline(model, budget_s=20.0):
-    """Oracle (oracle/lama_oracle.py = the reference's arithmetic on torch-CPU) on a bounded sample:
-    batch-1 loop over 512x512 images as bin/predict.py does, default torch threading."""
-    from oracle import lama_oracle as O
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+CPU_THREADS_CAP = 32      # oneDNN / MKL stop scaling (and oversubscribe) far below the 128-256 logical cores of the GPU box
+
+
+def _cpu_state(model=None):
+    from oracle import lama_oracle as O     # test infrastructure, used here as the CPU baseline only (never on the GPU path)
     cfg = {k: v for k, v in BIG_LAMA.items() if k != 'kind'}
+    if model is None:
+        model = build_model('cpu', L.PREC_F32, to_device=False)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    return O, sd, cfg
+
+
+def cpu_baseline(model, budget_s=10.0):
+    """Oracle (oracle/lama_oracle.py = the reference's arithmetic on torch-CPU, same oneDNN / MKL kernels) on a bounded sample of
+    the workload, three modes; `value` is the faithful bin/predict.py mode (batch-1 loop)."""
+    import subprocess
+    O, sd, cfg = _cpu_state(model)
+    ncpu = os.cpu_count() or 1
+    nthr = max(1, min(CPU_THREADS_CAP, ncpu))
+    torch.set_num_threads(nthr)
     img, mask = synthetic_batch('cpu', 1234)
-    n, t_used = 0, 0.0
     with torch.no_grad():
         O.training_module_forward(dict(image=img[:1, :, :128, :128].clone(), mask=mask[:1, :, :128, :128].clone()), sd, cfg)  # warm-up
+        n, t_used = 0, 0.0
         while n < BATCH and (n < 2 or t_used < budget_s):
             t0 = time.perf_counter()
             O.training_module_forward(dict(image=img[n:n + 1].clone(), mask=mask[n:n + 1].clone()), sd, cfg)
             t_used += time.perf_counter() - t0
             n += 1
-    return dict(value=round(n / t_used, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+        nb = 4
+        t0 = time.perf_counter()
+        O.training_module_forward(dict(image=img[:nb].clone(), mask=mask[:nb].clone()), sd, cfg)
+        t_b = time.perf_counter() - t0
+    modes = {'batch1_loop': dict(images_per_s=round(n / t_used, 4), images=n, threads=nthr, seconds=round(t_used, 1)),
+             'batched_forward': dict(images_per_s=round(nb / t_b, 4), images=nb, threads=nthr, seconds=round(t_b, 1))}
+    try:    # "as intended by bin/predict.py:16-20": one thread; the variable must be set before torch is imported -> subprocess
+        env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-one-thread-leg'], env=env, capture_output=True, text=True, timeout=180)
+        modes['omp_num_threads_1'] = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001
+        modes['omp_num_threads_1'] = dict(error=repr(e)[:200])
+    return dict(value=round(n / t_used, 4), unit='images/s', cores=nthr, kind='port',
                 sample=f'{n} of the {BATCH} 512x512 images, batch-1 loop (bin/predict.py mode), oracle/lama_oracle.py '
-                       f'(reference arithmetic on torch-CPU {torch.__version__}), {t_used:.1f} s, host has {os.cpu_count()} logical cores')
+                       f'(reference arithmetic on torch-CPU {torch.__version__}), {t_used:.1f} s, torch threads capped at {nthr} of '
+                       f'{ncpu} logical cores', modes=modes)
+
+
+def cpu_one_thread_leg():
+    """Child of cpu_baseline(): OMP_NUM_THREADS=1 was set before torch was imported ("as intended" by bin/predict.py:16-20); one
+    512 x 512 image through the oracle."""
+    torch.set_num_threads(1)
+    O, sd, cfg = _cpu_state(None)
+    img, mask = synthetic_batch('cpu', 1234, batch=1)
+    with torch.no_grad():
+        O.training_module_forward(dict(image=img[:, :, :64, :64].clone(), mask=mask[:, :, :64, :64].clone()), sd, cfg)
+        t0 = time.perf_counter()
+        O.training_module_forward(dict(image=img.clone(), mask=mask.clone()), sd, cfg)
+        dt = time.perf_counter() - t0
+    print(json.dumps(dict(images_per_s=round(1.0 / dt, 4), images=1, threads=torch.get_num_threads(), seconds=round(dt, 1))), flush=True)
+
+
+def eager_leg(steps=5):
+    """Child of main(): BASELINE configs[1]'s comparator -- the same generator as PyTorch-ROCm EAGER ops on this GPU (torch conv2d /
+    conv_transpose2d = MIOpen, batch_norm, torch.fft.rfftn / irfftn = rocFFT), i.e. the oracle's functional restatement of the
+    reference module with its tensors on cuda, fp32, 8 x 512^2, same mask-compose / blend glue, no u8 / gather."""
+    O, sd, cfg = _cpu_state(None)
+    dev = torch.device('cuda', 0)
+    sd = {k: v.to(dev) for k, v in sd.items()}
+    img, mask = synthetic_batch(dev, 1234)
+    torch.backends.cudnn.benchmark = False
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.training_module_forward(dict(image=img.clone(), mask=mask.clone()), sd, cfg)      # MIOpen solver search / kernel JIT
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t0
+        O.training_module_forward(dict(image=img.clone(), mask=mask.clone()), sd, cfg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            O.training_module_forward(dict(image=img.clone(), mask=mask.clone()), sd, cfg)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    print(json.dumps(dict(value=round(BATCH / dt, 2), unit='images/s', ms_per_step=round(dt * 1e3, 2), steps=steps, dtype='f32',
+                          first_call_s=round(t_first, 1), kind='port',
+                          note=f'oracle/lama_oracle.py on torch {torch.__version__} ROCm eager (MIOpen + rocFFT), same GPU, outside the timed region')),
+          flush=True)
+
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a torch.distributed environment: re-execute under torch.distributed.run (one rank per GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -157,7 +263,16 @@ def main():
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-fp32 timing leg')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-eager-leg', action='store_true', help='skip the PyTorch-ROCm eager comparator (subprocess)')
+    ap.add_argument('--cpu-one-thread-leg', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--eager-leg', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_one_thread_leg:
+        return cpu_one_thread_leg()
+    if args.eager_leg:
+        return eager_leg()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -168,9 +283,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
+    if args.gpus != world and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus = {world}', file=sys.stderr)
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     precision = L.PREC_NAMES[args.precision]
@@ -208,13 +322,36 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # the same K steps fed from / drained to pinned HOST buffers (SURVEY.md 8(d) "includes H2D/D2H"): fp32 image + mask in, u8 out,
+    # copies on the compute stream (serial, not overlapped).  Reported beside `value`, never as `value`.
+    dt_pcie = None
+    if world == 1:
+        h_img, h_mask = img.cpu().pin_memory(), mask.cpu().pin_memory()
+        h_u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8).pin_memory()
+        d_img, d_mask = torch.empty_like(img), torch.empty_like(mask)
+
+        def step_pcie():
+            d_img.copy_(h_img, non_blocking=True)
+            d_mask.copy_(h_mask, non_blocking=True)
+            out = model(dict(image=d_img, mask=d_mask))
+            lib.quantize_u8_hwc(L.view(out['inpainted']), u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
+            h_u8.copy_(u8, non_blocking=True)
+
+        step_pcie()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_pcie()
+        torch.cuda.synchronize()
+        dt_pcie = time.perf_counter() - t1
+
     # instrumented eager steps: per-kernel durations with HIP events on the launch stream
     roof = roof_ffc = None
     kern = {}
     if rank == 0:
         model.generator.use_graph = False
         model.generator.overlap_streams = False     # per-kernel events need every launch on the current stream
-        model.generator._plans = {}
+        model.generator._plans.clear()
         step()
         torch.cuda.synchronize()
         timer.on = True
@@ -268,11 +405,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model)
 
+    eager = None
+    if rank == 0 and world == 1 and not args.no_eager_leg and BATCH == 8 and RES == 512:
+        import subprocess
+        try:
+            torch.cuda.empty_cache()
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), '--eager-leg'], capture_output=True, text=True, timeout=420)
+            eager = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:      # noqa: BLE001
+            eager = dict(error=repr(e)[:300])
+
     if rank == 0:
         total_images = world * BATCH * args.steps
         line = {
             'metric': f'inpainted images/sec at {RES}x{RES} big-lama',
-            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'n_ranks_seen': (dist.get_world_size() if world > 1 else 1),
+            'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if precision == L.PREC_F32 else f'f32 (3-term {args.precision[:-2]} split on the 16-bit MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',
             'config': {'workload': f'big-lama FFCResNetGenerator {RES}x{RES} batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
@@ -280,6 +428,11 @@ def main():
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'hip_graph': not args.no_graph, 'precision': args.precision},
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
+            'pytorch_rocm_eager': eager,
+            'value_with_h2d_d2h': None if dt_pcie is None else dict(
+                value=round(BATCH * args.steps / dt_pcie, 3), unit='images/s', ms_per_step=round(dt_pcie / args.steps * 1e3, 3),
+                note=f'pinned host fp32 image+mask in ({BATCH * 4 * RES * RES * 4 / 1e6:.1f} MB), u8 out ({BATCH * 3 * RES * RES / 1e6:.1f} MB) '
+                     'per step over PCIe on the compute stream, not overlapped'),
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['total_us'])},
         }
         print(json.dumps(line), flush=True)

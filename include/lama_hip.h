@@ -9,7 +9,8 @@
  *     >0 = hipError_t of the failing runtime call.  Nothing throws, exits or synchronises the host.
  *   - all pointers are DEVICE pointers owned by the caller (inputs, outputs, packed weights and
  *     workspace).  The library allocates nothing and keeps no state; every launch is asynchronous on
- *     the given hipStream_t (passed as void*) and is hipGraph-capturable.
+ *     the given hipStream_t (passed as void*) and is hipGraph-capturable.  The library reads no environment variable
+ *     (kernel-selection overrides, ablations and tracers exist only in the -DLAMA_PROFILING build used by tools/).
  *   - activations are fp32 NCHW "views": element (b,c,y,x) of a lama_tensor lives at
  *     ptr[b*batch_stride + (c*H + y)*W + x]; batch_stride lets a view address a channel slice of a
  *     wider buffer (the bottleneck state keeps x_l | x_g in one 512-channel buffer, which makes
@@ -24,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 100
+#define LAMA_HIP_VERSION 101
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -76,6 +77,11 @@ typedef struct lama_conv2d_args {
     lama_tensor y;
     int32_t batch;
     int32_t precision; /* LAMA_PREC_*                                                    */
+    /* Range watch of LAMA_PREC_F16X3 (ignored by the other precisions; NULL = off).  The fp16 split represents |x| <= 65504
+     * only: a kernel that meets a larger activation (or a NaN) while splitting x / x2 ORs 1 into *range_flag (device
+     * uint32, zeroed by the caller); its output is then garbage and the caller re-runs with LAMA_PREC_BF16X3 (fp32 exponent
+     * range, 16 mantissa bits) or LAMA_PREC_F32.  The weights are range-checked by the host at pack time instead. */
+    uint32_t* range_flag;
 } lama_conv2d_args;
 
 int lama_version(void);
@@ -106,11 +112,12 @@ size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w);
 
 /* FourierUnit.forward (ffc.py:76-113) in one call: y = [x +] irfft2( relu( W' rfft2(x) + b ) ).
  * w_packed = lama_conv2d_pack_weight(conv_layer.weight [2C,2C,1,1], bn scale); bias = bn shift.
- * workspace >= lama_fourier_unit_workspace_bytes. add_input != 0 fuses SpectralTransform's x + fu(x). */
+ * workspace >= lama_fourier_unit_workspace_bytes. add_input != 0 fuses SpectralTransform's x + fu(x).
+ * range_flag: as in lama_conv2d_args (the spectrum's DC bin grows with sqrt(h*w): the first tensor to leave the fp16 range). */
 size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w);
 int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
                           const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision, void* workspace,
-                          size_t workspace_bytes);
+                          size_t workspace_bytes, uint32_t* range_flag);
 
 /* masked_img = cat(img*(1-mask), mask), trainers/default.py:59,67-68.  img [B,3,H,W], mask [B,1,H,W] -> out [B,4,H,W] */
 int lama_mask_compose_fwd(void* stream, const lama_tensor* image, const lama_tensor* mask, const lama_tensor* out,

@@ -15,6 +15,7 @@ import torch
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3 = 0, 1, 2
+ABI_VERSION = 101      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -22,6 +23,12 @@ _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libl
 
 class LamaError(RuntimeError):
     pass
+
+
+class LamaRangeError(LamaError):
+    """A weight or an activation left the range of the fp16 split (|x| <= 65504): re-run with PREC_BF16X3 / PREC_F32."""
+
+F16_MAX = 65504.0
 
 
 class Tensor4(C.Structure):
@@ -35,7 +42,8 @@ class Conv2dArgs(C.Structure):
                 ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
                 ('pad_mode', C.c_int32), ('transposed', C.c_int32),
                 ('x2', Tensor4), ('w2_packed', C.c_void_p), ('bias', C.c_void_p), ('act', C.c_int32),
-                ('resid', Tensor4), ('y', Tensor4), ('batch', C.c_int32), ('precision', C.c_int32)]
+                ('resid', Tensor4), ('y', Tensor4), ('batch', C.c_int32), ('precision', C.c_int32),
+                ('range_flag', C.c_void_p)]
 
 
 def view(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Tensor4:
@@ -52,7 +60,10 @@ def view(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Ten
 
 
 class LamaLib:
-    def __init__(self, path: Optional[str] = None):
+    def __init__(self, path: Optional[str] = None, host_emulated: bool = False):
+        """``host_emulated``: the library is the x86 build of the kernel sources (tests/hipemu) and takes HOST pointers; the
+        real library takes device pointers only and every wrapper below refuses CPU tensors."""
+        self.host_emulated = host_emulated
         path = path or os.environ.get('LAMA_HIP_LIB') or _DEFAULT     # LAMA_HIP_LIB: A/B-testing another build of the same ABI
         if not os.path.exists(path):
             raise LamaError(f'{path} not found: build it with `python -m lama_amd.build` '
@@ -79,7 +90,7 @@ class LamaLib:
         L.lama_fourier_unit_workspace_bytes.restype = sz
         L.lama_fourier_unit_workspace_bytes.argtypes = [i32] * 4
         L.lama_fourier_unit_fwd.restype = C.c_int
-        L.lama_fourier_unit_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz]
+        L.lama_fourier_unit_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz, vp]
         L.lama_mask_compose_fwd.restype = C.c_int
         L.lama_mask_compose_fwd.argtypes = [vp, T, T, T, i32]
         L.lama_blend_fwd.restype = C.c_int
@@ -90,8 +101,8 @@ class LamaLib:
         L.lama_affine_act_fwd.argtypes = [vp, T, vp, vp, i32, T, i32]
         L.lama_reflect_pad_fwd.restype = C.c_int
         L.lama_reflect_pad_fwd.argtypes = [vp, T, i32, T, i32]
-        if L.lama_version() != 100:
-            raise LamaError(f'{path}: ABI version {L.lama_version()} != 100')
+        if L.lama_version() != ABI_VERSION:
+            raise LamaError(f'{path}: ABI version {L.lama_version()} != {ABI_VERSION}')
 
     # -- helpers -------------------------------------------------------------------------------
     def check(self, rc: int, what: str):
@@ -106,7 +117,12 @@ class LamaLib:
     def pack_conv_weight(self, w: torch.Tensor, scale: Optional[torch.Tensor], stride: int = 1, transposed: bool = False,
                          precision: int = PREC_F32) -> torch.Tensor:
         """Reference-layout conv weight (+ folded BN scale) -> packed device buffer."""
+        if not self.host_emulated and not w.is_cuda:
+            raise LamaError('pack_conv_weight: the weights are on the CPU (e.g. after load_checkpoint(map_location="cpu")): move the '
+                            'module to the GPU first (model.to("cuda")) -- the HIP kernels dereference device pointers only')
         w = w.contiguous().float()
+        if scale is not None and scale.device != w.device:
+            raise LamaError(f'pack_conv_weight: weight on {w.device} but BatchNorm scale on {scale.device}')
         if transposed:
             cin, cout, kh, kw = w.shape
         else:
@@ -114,8 +130,14 @@ class LamaLib:
         nbytes = self._l.lama_conv2d_packed_weight_bytes(cout, cin, kh, kw, stride, int(transposed), precision)
         if nbytes <= 0:
             raise LamaError(f'unsupported conv geometry {tuple(w.shape)} stride={stride} transposed={transposed}')
+        if precision == PREC_F16X3 and w.numel():
+            # the fp16 split of the WEIGHTS is checked here, once (activations: range_flag of lama_conv2d_args)
+            ws = w if scale is None else w * (scale.float().view(1, -1, 1, 1) if transposed else scale.float().view(-1, 1, 1, 1))
+            amax = float(ws.abs().max())
+            if not amax <= F16_MAX:
+                raise LamaRangeError(f'folded conv weight |w| max {amax:.3g} exceeds the fp16 split range ({F16_MAX}); use bf16x3 or f32')
         dst = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
-        sc = None if scale is None else scale.contiguous().float().to(w.device)
+        sc = None if scale is None else scale.contiguous().float()
         self.check(self._l.lama_conv2d_pack_weight(self.stream_of(w), w.data_ptr(), None if sc is None else sc.data_ptr(),
                                                    cout, cin, kh, kw, stride, int(transposed), precision, dst.data_ptr()),
                    'lama_conv2d_pack_weight')
@@ -126,7 +148,8 @@ class LamaLib:
     def conv2d(self, x: Tensor4, w_packed: torch.Tensor, y: Tensor4, batch: int, k: int, stride: int = 1, pad: int = 0,
                pad_mode: int = PAD_REFLECT, transposed: bool = False, bias: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, resid: Optional[Tensor4] = None, x2: Optional[Tensor4] = None,
-               w2_packed: Optional[torch.Tensor] = None, precision: int = PREC_F32, stream: int = 0):
+               w2_packed: Optional[torch.Tensor] = None, precision: int = PREC_F32, stream: int = 0,
+               range_flag: Optional[torch.Tensor] = None):
         a = Conv2dArgs()
         a.x, a.w_packed = x, w_packed.data_ptr()
         a.kh = a.kw = k
@@ -138,6 +161,7 @@ class LamaLib:
         if resid is not None:
             a.resid = resid
         a.y, a.batch, a.precision = y, batch, precision
+        a.range_flag = None if range_flag is None else range_flag.data_ptr()
         self.check(self._l.lama_conv2d_fwd(stream, C.byref(a)), 'lama_conv2d_fwd')
 
     # -- fft -------------------------------------------------------------------------------------
@@ -159,9 +183,10 @@ class LamaLib:
         return int(self._l.lama_fourier_unit_workspace_bytes(b, c, h, w))
 
     def fourier_unit(self, x: Tensor4, w_packed: torch.Tensor, bias: torch.Tensor, y: Tensor4, batch: int, add_input: bool,
-                     ws: torch.Tensor, precision: int = PREC_F32, stream: int = 0):
+                     ws: torch.Tensor, precision: int = PREC_F32, stream: int = 0, range_flag: Optional[torch.Tensor] = None):
         self.check(self._l.lama_fourier_unit_fwd(stream, C.byref(x), w_packed.data_ptr(), bias.data_ptr(), C.byref(y), batch,
-                                                 int(add_input), precision, ws.data_ptr(), ws.numel() * ws.element_size()),
+                                                 int(add_input), precision, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                                 None if range_flag is None else range_flag.data_ptr()),
                    'lama_fourier_unit_fwd')
 
     # -- elementwise -------------------------------------------------------------------------------

@@ -17,6 +17,9 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'liblama_hip.so')
+# Same sources with -DLAMA_PROFILING: kernel-selection overrides, timing ablations and timeline tracers read from the environment.
+# Only tools/ and the forced-path GPU tests load it (LAMA_HIP_LIB / LamaLib(path)); the product never does.
+LIB_PROF = os.path.join(LIBDIR, 'liblama_hip_prof.so')
 SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'fft.hip', 'elementwise.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'),
            os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
@@ -31,46 +34,59 @@ def _hipcc() -> str:
     raise RuntimeError('hipcc not found: liblama_hip.so cannot be built')
 
 
-def _digest(paths) -> str:
+def _digest(paths, extra_flags=()) -> str:
     h = hashlib.sha256()
     for p in paths:
         with open(p, 'rb') as f:
             h.update(f.read())
-    h.update(' '.join(HIPCC_FLAGS).encode())
+    h.update(' '.join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
     return h.hexdigest()
 
 
 def _compile(args):
-    src, obj, hipcc = args
-    cmd = [hipcc, *HIPCC_FLAGS, '-c', src, '-o', obj]
+    src, obj, hipcc, extra = args
+    cmd = [hipcc, *HIPCC_FLAGS, *extra, '-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
     return obj
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP source for gfx950 and link lama_amd/lib/liblama_hip.so; returns its path."""
+def _build_one(lib: str, extra_flags, force: bool, verbose: bool) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    stamp = os.path.join(LIBDIR, 'liblama_hip.sha256')
-    dig = _digest(srcs + HEADERS)
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
-        return LIB
+    tag = os.path.splitext(os.path.basename(lib))[0]
+    stamp = os.path.join(LIBDIR, tag + '.sha256')
+    dig = _digest(srcs + HEADERS, extra_flags)
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return lib
     hipcc = _hipcc()
-    objdir = os.path.join(LIBDIR, 'obj')
+    objdir = os.path.join(LIBDIR, 'obj', tag)
     os.makedirs(objdir, exist_ok=True)
-    jobs = [(s, os.path.join(objdir, os.path.basename(s) + '.o'), hipcc) for s in srcs]
+    jobs = [(s, os.path.join(objdir, os.path.basename(s) + '.o'), hipcc, extra_flags) for s in srcs]
     if verbose:
-        print(f'[lama_amd.build] hipcc {len(jobs)} sources for gfx950 ...', file=sys.stderr)
+        print(f'[lama_amd.build] hipcc {len(jobs)} sources for gfx950 -> {os.path.basename(lib)} ...', file=sys.stderr)
     with concurrent.futures.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(_compile, jobs))
-    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB, *objs], capture_output=True, text=True)
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
     with open(stamp, 'w') as f:
         f.write(dig)
-    return LIB
+    return lib
+
+
+def build(force: bool = False, verbose: bool = True, profiling: bool = True) -> str:
+    """Compile every HIP source for gfx950 and link lama_amd/lib/liblama_hip.so (the product) and, with ``profiling``,
+    lama_amd/lib/liblama_hip_prof.so (same sources + -DLAMA_PROFILING, for tools/ and the forced-path tests); returns the
+    product's path."""
+    if not profiling:
+        return _build_one(LIB, [], force, verbose)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
+        f1 = ex.submit(_build_one, LIB, [], force, verbose)
+        f2 = ex.submit(_build_one, LIB_PROF, ['-DLAMA_PROFILING'], force, verbose)
+        f2.result()
+        return f1.result()
 
 
 if __name__ == '__main__':

@@ -18,6 +18,18 @@ extern __shared__ __attribute__((aligned(16))) char lama_smem[];
         if (e__ != hipSuccess) return (int)e__;  \
     } while (0)
 
+// Kernel-selection overrides, timing ablations (which produce WRONG results by design) and timeline tracers (which write to a
+// device address taken from the environment) are hooks of tools/ and of the forced-path tests: they exist only in builds with
+// -DLAMA_PROFILING (lama_amd/lib/liblama_hip_prof.so, tests/hipemu).  The shipped liblama_hip.so reads no environment variable.
+#ifdef LAMA_PROFILING
+#include <stdlib.h>
+static inline int lama_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static inline unsigned long long lama_env_u64(const char* name) { const char* e = getenv(name); return e ? strtoull(e, nullptr, 0) : 0ull; }
+#else
+static inline constexpr int lama_env_int(const char*, int dflt) { return dflt; }
+static inline constexpr unsigned long long lama_env_u64(const char*) { return 0ull; }
+#endif
+
 static inline int lama_ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t lama_ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int lama_round_up(int a, int b) { return lama_ceil_div(a, b) * b; }

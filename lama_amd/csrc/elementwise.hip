@@ -230,7 +230,7 @@ extern "C" size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, in
 
 extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
                                      const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
-                                     void* workspace, size_t workspace_bytes) {
+                                     void* workspace, size_t workspace_bytes, uint32_t* range_flag) {
     if (!x || !y || !x->ptr || !y->ptr || !w_packed || batch <= 0) return LAMA_ERR_BAD_ARG;
     if (x->C != y->C || x->H != y->H || x->W != y->W) return LAMA_ERR_BAD_ARG;
     const int C = x->C, h = x->H, w = x->W, wf = w / 2 + 1;
@@ -254,6 +254,7 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
     a.y = s2;
     a.batch = batch;
     a.precision = precision;
+    a.range_flag = range_flag;
     rc = lama_conv2d_fwd(stream, &a);
     if (rc) return rc;
     return lama_irfft2_fwd(stream, &s2, add_input ? x : nullptr, y, batch, fws, fws_bytes);

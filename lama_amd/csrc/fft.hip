@@ -1266,8 +1266,7 @@ size_t fft_lds_bytes(int h, int w, int ppw) {
 // planes one workgroup of the sized one-plane kernels walks sequentially (request of plane s + 1 under the transform of
 // plane s); LAMA_FFT_SEQ overrides it (1 = one plane per workgroup; A/B runs of the profiling tools and the tests)
 int fft_seq(int nplanes) {
-    const char* e = getenv("LAMA_FFT_SEQ");
-    const int want = e ? atoi(e) : 1;
+    const int want = lama_env_int("LAMA_FFT_SEQ", 1);   // a constant in the product build; the profiling build reads it per launch (tests switch it)
     if (want >= 3 && nplanes % 3 == 0) return 3;
     if (want >= 2 && nplanes % 2 == 0) return 2;
     return 1;
@@ -1275,15 +1274,14 @@ int fft_seq(int nplanes) {
 
 // profiling tools only: LAMA_FFT_TRACE = device address of (workgroups * 16) int64 -> per-workgroup phase timeline of the 64 x 64 kernels
 long long* fft_trace_buf() {
-    static const unsigned long long tr = [] { const char* e = getenv("LAMA_FFT_TRACE"); return e ? strtoull(e, nullptr, 0) : 0ull; }();
+    static const unsigned long long tr = lama_env_u64("LAMA_FFT_TRACE");
     return reinterpret_cast<long long*>(tr);
 }
 
 // one-buffer 64 x 64 kernels (rfft2_ip64_kernel / irfft2_ip64_kernel); LAMA_FFT_INPLACE=0 keeps the two-buffer kernels (A/B
 // runs of the profiling tools and the tests)
 bool fft_inplace() {
-    const char* e = getenv("LAMA_FFT_INPLACE");
-    return !(e && atoi(e) == 0);
+    return lama_env_int("LAMA_FFT_INPLACE", 1) != 0;   // a constant in the product build
 }
 
 bool fft_args_ok(const lama_tensor* real, const lama_tensor* spec, int batch) {
@@ -1329,11 +1327,13 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
             hipLaunchKernelGGL((rfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
         else if (p.h == 128 && p.w == 128 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
             hipLaunchKernelGGL((rfft2_ipn_kernel<128>), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), st, p);
+#ifdef LAMA_PROFILING
         else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
         else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
         else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 3>), gseq, blk, lds, st, p);
+#endif
         else if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
         else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((rfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
         else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
@@ -1397,11 +1397,13 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
             hipLaunchKernelGGL((irfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
         else if (p.h == 128 && p.w == 128 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
             hipLaunchKernelGGL((irfft2_ipn_kernel<128>), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), st, p);
+#ifdef LAMA_PROFILING
         else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
         else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
         else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
         else if (seq == 3 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 3>), gseq, blk, lds, st, p);
+#endif
         else if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
         else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((irfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
         else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);

@@ -18,11 +18,15 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import collections
+import contextlib
+import warnings
+
 import torch
 import torch.nn as nn
 
 from . import _lib as L
-from ._lib import LamaError
+from ._lib import LamaError, LamaRangeError
 
 _ACT = {'relu': L.ACT_RELU, 'sigmoid': L.ACT_SIGMOID, 'tanh': L.ACT_TANH, None: L.ACT_NONE}
 
@@ -89,11 +93,19 @@ def _check_input(x: torch.Tensor):
 class _Exec:
     """Where kernels run: the loaded library and the stream to launch on.  The default is the in-tree
     gfx950 library on the current torch stream; tests inject the host-emulated build of the same
-    sources (tests/hipemu) to exercise this host logic without a GPU."""
+    sources (tests/hipemu) to exercise this host logic without a GPU.
+
+    It also owns the RANGE WATCH of the fp16 split (lama_conv2d_args.range_flag): every public ``forward`` opens a
+    ``range_scope``; the conv / FourierUnit launches inside it hand the per-device flag to the kernels, and the outermost
+    scope reads it back when it closes (one 4-byte D2H per forward) and raises ``LamaRangeError`` if an activation beyond
+    65504 (or a NaN) was split -- FFCResNetGenerator.forward then falls back to PREC_BF16X3."""
 
     def __init__(self, lib: Optional[L.LamaLib] = None):
         self._lib = lib
         self.injected = lib is not None
+        self._flags = {}
+        self._depth = 0
+        self._cur_flag = None
 
     @property
     def lib(self) -> L.LamaLib:
@@ -107,6 +119,38 @@ class _Exec:
     def check(self, x: torch.Tensor):
         if not self.injected:
             _check_input(x)
+
+    @contextlib.contextmanager
+    def range_scope(self, t: torch.Tensor, precision: int):
+        outer = self._depth == 0
+        if outer and precision == L.PREC_F16X3:
+            key = str(t.device)
+            if key not in self._flags:
+                self._flags[key] = torch.zeros(1, dtype=torch.int32, device=t.device)
+            self._cur_flag = self._flags[key]
+        self._depth += 1
+        try:
+            yield
+        except BaseException:
+            self._depth -= 1
+            if outer:
+                self._cur_flag = None
+            raise
+        self._depth -= 1
+        if outer:
+            flag, self._cur_flag = self._cur_flag, None
+            if flag is not None and int(flag.item()) != 0:
+                flag.zero_()
+                raise LamaRangeError('an activation left the range of the fp16 split (|x| > 65504 or NaN) in this forward; '
+                                     're-run with precision bf16x3 (fp32 exponent range) or f32')
+
+    def conv2d(self, *a, **kw):
+        flag = self._cur_flag if kw.get('precision') == L.PREC_F16X3 else None
+        self.lib.conv2d(*a, range_flag=flag, **kw)
+
+    def fourier_unit(self, *a, precision: int = L.PREC_F32, stream: int = 0):
+        flag = self._cur_flag if precision == L.PREC_F16X3 else None
+        self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag)
 
 
 _DEFAULT_EXEC = _Exec()
@@ -185,7 +229,7 @@ class FourierUnit(_HipModule):
 
     def run(self, x: L.Tensor4, y: L.Tensor4, batch: int, add_input: bool, ws: torch.Tensor, stream: int):
         wp, shift = self._pack()
-        self._exec.lib.fourier_unit(x, wp, shift, y, batch, add_input, ws, self.precision, stream)
+        self._exec.fourier_unit(x, wp, shift, y, batch, add_input, ws, precision=self.precision, stream=stream)
 
     def workspace(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
@@ -196,7 +240,8 @@ class FourierUnit(_HipModule):
         self._exec.check(x)
         x = x.contiguous()
         y = torch.empty_like(x)
-        self.run(L.view(x), L.view(y), x.shape[0], add_input, self.workspace(x), self._exec.stream(x))
+        with self._exec.range_scope(x, self.precision):
+            self.run(L.view(x), L.view(y), x.shape[0], add_input, self.workspace(x), self._exec.stream(x))
         return y
 
 
@@ -229,23 +274,24 @@ class SpectralTransform(_HipModule):
     def run_front(self, xg: L.Tensor4, x1: torch.Tensor, t: torch.Tensor, ws: torch.Tensor, batch: int, stream: int):
         """x1 = relu(bn(conv1(xg))); t = x1 + fu(x1).  (conv2 is fused by the caller.)"""
         pk = self._packed
-        self._exec.lib.conv2d(xg, pk['w1'], L.view(x1), batch, 1, bias=pk['b1'], act=L.ACT_RELU, precision=self.precision, stream=stream)
+        self._exec.conv2d(xg, pk['w1'], L.view(x1), batch, 1, bias=pk['b1'], act=L.ACT_RELU, precision=self.precision, stream=stream)
         self.fu.run(L.view(x1), L.view(t), batch, True, ws, stream)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._exec.check(x)
         x = x.contiguous()
-        if self._packed is None or self._packed.get('fused_scale'):
-            self._packed = None
-            self._pack(None)
         b, _, h, w = x.shape
         half = self.conv2.in_channels
-        x1 = torch.empty(b, half, h, w, device=x.device, dtype=torch.float32)
-        t = torch.empty_like(x1)
-        st = self._exec.stream(x)
-        self.run_front(L.view(x), x1, t, self.fu.workspace(x1), b, st)
-        y = torch.empty(b, self.conv2.out_channels, h, w, device=x.device, dtype=torch.float32)
-        self._exec.lib.conv2d(L.view(t), self._packed['w2'], L.view(y), b, 1, precision=self.precision, stream=st)
+        with self._exec.range_scope(x, self.precision):
+            if self._packed is None or self._packed.get('fused_scale') not in (None, 'none'):
+                self._packed = None
+                self._pack(None)
+            x1 = torch.empty(b, half, h, w, device=x.device, dtype=torch.float32)
+            t = torch.empty_like(x1)
+            st = self._exec.stream(x)
+            self.run_front(L.view(x), x1, t, self.fu.workspace(x1), b, st)
+            y = torch.empty(b, self.conv2.out_channels, h, w, device=x.device, dtype=torch.float32)
+            self._exec.conv2d(L.view(t), self._packed['w2'], L.view(y), b, 1, precision=self.precision, stream=st)
         return y
 
 
@@ -291,14 +337,110 @@ class FFC(_HipModule):
         if in_cg > 0 and (stride != 1 or kernel_size != 3):
             raise NotImplementedError('FFC with a global input is implemented for 3x3 stride-1 layers (the resnet blocks)')
 
+    # -- packing -------------------------------------------------------------------------------------
+    def pack(self, sl=None, bl=None, sg=None, bg=None):
+        """Packed weights of the four branches; (sl, bl) / (sg, bg) = folded BatchNorm scale / shift of the local / global
+        outputs (None = the bare FFC of ffc.py:205-225: no BatchNorm, no bias)."""
+        f, lib, prec = self, self._exec.lib, self.precision
+        pk = {}
+        dev = f.convl2l.weight.device if isinstance(f.convl2l, nn.Conv2d) else f.convl2g.weight.device
+
+        def cat_opt(ts, n):
+            ts = [t if t is not None else None for t in ts]
+            return None if any(t is None for t in ts) else torch.cat(ts, 0).contiguous()
+
+        if f.in_cg == 0:
+            # every output comes from x_l: ONE conv with [convl2l ; convl2g] stacked along Cout
+            ws, ss, bs = [], [], []
+            if f.out_cl:
+                ws.append(f.convl2l.weight.detach()); ss.append(sl); bs.append(bl)
+            if f.out_cg:
+                ws.append(f.convl2g.weight.detach()); ss.append(sg); bs.append(bg)
+            pk['w_all'] = lib.pack_conv_weight(torch.cat(ws, 0), cat_opt(ss, 0), stride=f.stride, precision=prec)
+            pk['b_all'] = cat_opt(bs, 0)
+        else:
+            # local output: conv over the whole state buffer [x_l | x_g] with [convl2l , convg2l] stacked along Cin
+            w_lout = torch.cat([f.convl2l.weight.detach(), f.convg2l.weight.detach()], dim=1)
+            pk['w_lout'] = lib.pack_conv_weight(w_lout, sl, precision=prec)
+            pk['b_l'] = None if bl is None else bl.contiguous()
+            pk['w_l2g'] = lib.pack_conv_weight(f.convl2g.weight.detach(), sg, precision=prec)
+            pk['b_g'] = None if bg is None else bg.contiguous()
+            st = f.convg2g
+            st._packed = None
+            st._pack(sg)
+            st._packed['fused_scale'] = id(sg) if sg is not None else 'none'
+            st.fu._pack()
+        del dev
+        return pk
+
+    # -- launch --------------------------------------------------------------------------------------
+    def launch(self, pk: dict, act: int, src: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict],
+               resid: Optional[torch.Tensor] = None, extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None):
+        """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous), as 1 launch (no global
+        input) or 6 launches (conv1x1, rfft2, spectral conv1x1, irfft2+add, fused local conv, fused global conv).
+
+        ``side``: optional second HIP stream.  The spectral branch (conv1 -> rfft2 -> spectral 1x1 -> irfft2, HBM/latency
+        bound, small LDS footprint) then runs on it concurrently with the MFMA-bound local 3x3 conv of the main stream; the
+        two join before the global conv that consumes both.  Works inside hipGraph capture (fork/join via events)."""
+        f, ex, prec = self, self._exec, self.precision
+        B = src.shape[0]
+        st = ex.stream(src)
+        pad = f.padding + extra_pad
+        if f.in_cg == 0:
+            ex.conv2d(L.view(src), pk['w_all'], L.view(dst), B, f.kernel_size, f.stride, pad, L.PAD_REFLECT, False, pk['b_all'],
+                      act, None if resid is None else L.view(resid), precision=prec, stream=st)
+            return
+        cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
+        spec = f.convg2g
+        if side is not None and src.is_cuda:
+            main = torch.cuda.current_stream(src.device)
+            side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream)
+            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
+                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+            main.wait_stream(side)                      # join: t is ready for the global conv
+        else:
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st)
+            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
+                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+        ex.conv2d(L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], act,
+                  None if resid is None else L.view(resid, ocl, ocg), x2=L.view(scratch['t']), w2_packed=spec._packed['w2'],
+                  precision=prec, stream=st)
+
+    def out_shape(self, src_shape, extra_pad: int = 0):
+        B, _, H, W = src_shape
+        pad = self.padding + extra_pad
+        Ho = (H + 2 * pad - self.kernel_size) // self.stride + 1
+        Wo = (W + 2 * pad - self.kernel_size) // self.stride + 1
+        return (B, self.out_cl + self.out_cg, Ho, Wo)
+
+    def make_scratch(self, src_shape, device) -> Optional[dict]:
+        if self.in_cg == 0:
+            return None
+        B, _, H, W = src_shape
+        half = self.convg2g.conv2.in_channels
+        x1 = torch.empty(B, half, H, W, device=device, dtype=torch.float32)
+        return dict(x1=x1, t=torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
+
     def forward(self, x):
-        raise NotImplementedError('lama_amd.ffc.FFC is launched through FFC_BN_ACT (BatchNorm/activation are fused into its '
-                                  'kernels); call the enclosing FFC_BN_ACT instead')
+        """The bare FFC of ffc.py:205-225 (no BatchNorm, no activation): (x_l, x_g) -> (out_xl, out_xg), same launches as the
+        fused layer with unit scale, no bias and LAMA_ACT_NONE."""
+        x_l, x_g = x if type(x) is tuple else (x, 0)
+        self._exec.check(x_l)
+        src, cl, cg = _pair_buffer(x_l, x_g)
+        if cl != self.in_cl or cg != self.in_cg:
+            raise LamaError(f'FFC expected ({self.in_cl},{self.in_cg}) local/global channels, got ({cl},{cg})')
+        with self._exec.range_scope(src, self.precision):
+            if self._packed is None or (self.in_cg and (self.convg2g._packed or {}).get('fused_scale') != 'none'):
+                self._packed = self.pack()
+            dst = torch.empty(self.out_shape(src.shape), device=src.device, dtype=torch.float32)
+            self.launch(self._packed, L.ACT_NONE, src, dst, self.make_scratch(src.shape, src.device))
+        return (dst[:, :self.out_cl] if self.out_cl else 0), (dst[:, self.out_cl:] if self.out_cg else 0)
 
 
 class FFC_BN_ACT(_HipModule):
-    """ffc.py:228-255: FFC + BatchNorm (local, global) + activation, as 1 launch (no global branch) or
-    6 launches (conv1x1, rfft2, spectral conv1x1, irfft2+add, fused local conv, fused global conv)."""
+    """ffc.py:228-255: FFC + BatchNorm (local, global) + activation; BatchNorm(eval) is folded into the packed weights and the
+    epilogue bias, the activation (and the residual add of the enclosing block) runs in the conv epilogues (FFC.launch)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, ratio_gin, ratio_gout, stride=1, padding=0, dilation=1,
                  groups=1, bias=False, norm_layer=nn.BatchNorm2d, activation_layer=nn.Identity, padding_type='reflect',
@@ -319,86 +461,27 @@ class FFC_BN_ACT(_HipModule):
     def _pack(self):
         if self._packed is not None:
             return self._packed
-        f, lib, prec = self.ffc, self._exec.lib, self.precision
-        pk = {}
+        f = self.ffc
         sl, bl = _bn_fold(self.bn_l) if f.out_cl else (None, None)
         sg, bg = _bn_fold(self.bn_g) if f.out_cg else (None, None)
-        if f.in_cg == 0:
-            # every output comes from x_l: ONE conv with [convl2l ; convl2g] stacked along Cout
-            ws, ss, bs = [], [], []
-            if f.out_cl:
-                ws.append(f.convl2l.weight.detach()); ss.append(sl); bs.append(bl)
-            if f.out_cg:
-                ws.append(f.convl2g.weight.detach()); ss.append(sg); bs.append(bg)
-            pk['w_all'] = lib.pack_conv_weight(torch.cat(ws, 0), torch.cat(ss, 0), stride=f.stride, precision=prec)
-            pk['b_all'] = torch.cat(bs, 0).contiguous()
-        else:
-            # local output: conv over the whole state buffer [x_l | x_g] with [convl2l , convg2l] stacked along Cin
-            w_lout = torch.cat([f.convl2l.weight.detach(), f.convg2l.weight.detach()], dim=1)
-            pk['w_lout'] = lib.pack_conv_weight(w_lout, sl, precision=prec)
-            pk['b_l'] = bl.contiguous()
-            pk['w_l2g'] = lib.pack_conv_weight(f.convl2g.weight.detach(), sg, precision=prec)
-            pk['b_g'] = bg.contiguous()
-            st = f.convg2g
-            st._packed = None
-            st._pack(sg)
-            st._packed['fused_scale'] = True
-            st.fu._pack()
-        self._packed = pk
-        return pk
+        self._packed = f.pack(sl, bl, sg, bg)
+        self._packed['_sg'] = sg
+        f._packed = None         # a bare FFC.forward packs its own (unscaled) set
+        return self._packed
 
     # -- launch --------------------------------------------------------------------------------------
     def run(self, src: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], resid: Optional[torch.Tensor] = None,
             extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None):
-        """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous).
-
-        ``side``: optional second HIP stream.  The spectral branch (conv1 -> rfft2 -> spectral 1x1 -> irfft2, HBM/latency
-        bound, small LDS footprint) then runs on it concurrently with the MFMA-bound local 3x3 conv of the main stream; the
-        two join before the global conv that consumes both.  Works inside hipGraph capture (fork/join via events)."""
-        f, lib, prec = self.ffc, self._exec.lib, self.precision
-        if f.in_cg and not (f.convg2g._packed or {}).get('fused_scale'):
-            self._packed = None   # a stand-alone SpectralTransform.forward re-packed conv2 without bn_g
-        pk = self._pack()
-        B = src.shape[0]
-        st = self._exec.stream(src)
-        pad = f.padding + extra_pad
-        if f.in_cg == 0:
-            lib.conv2d(L.view(src), pk['w_all'], L.view(dst), B, f.kernel_size, f.stride, pad, L.PAD_REFLECT, False, pk['b_all'],
-                       self._act, None if resid is None else L.view(resid), precision=prec, stream=st)
-            return
-        cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
-        spec = f.convg2g
-        if side is not None and src.is_cuda:
-            main = torch.cuda.current_stream(src.device)
-            side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
-            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream)
-            lib.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], self._act,
-                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
-            main.wait_stream(side)                      # join: t is ready for the global conv
-        else:
-            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st)
-            lib.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], self._act,
-                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
-        lib.conv2d(L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], self._act,
-                   None if resid is None else L.view(resid, ocl, ocg), x2=L.view(scratch['t']), w2_packed=spec._packed['w2'],
-                   precision=prec, stream=st)
+        f = self.ffc
+        if f.in_cg and self._packed is not None and (f.convg2g._packed or {}).get('fused_scale') != id(self._packed.get('_sg')):
+            self._packed = None   # a stand-alone SpectralTransform.forward / FFC.forward re-packed conv2 without bn_g
+        f.launch(self._pack(), self._act, src, dst, scratch, resid, extra_pad, side)
 
     def out_shape(self, src_shape, extra_pad: int = 0):
-        f = self.ffc
-        B, _, H, W = src_shape
-        pad = f.padding + extra_pad
-        Ho = (H + 2 * pad - f.kernel_size) // f.stride + 1
-        Wo = (W + 2 * pad - f.kernel_size) // f.stride + 1
-        return (B, f.out_cl + f.out_cg, Ho, Wo)
+        return self.ffc.out_shape(src_shape, extra_pad)
 
     def make_scratch(self, src_shape, device) -> Optional[dict]:
-        f = self.ffc
-        if f.in_cg == 0:
-            return None
-        B, _, H, W = src_shape
-        half = f.convg2g.conv2.in_channels
-        x1 = torch.empty(B, half, H, W, device=device, dtype=torch.float32)
-        return dict(x1=x1, t=torch.empty_like(x1), ws=f.convg2g.fu.workspace(x1))
+        return self.ffc.make_scratch(src_shape, device)
 
     def forward(self, x, extra_pad: int = 0):
         x_l, x_g = x if type(x) is tuple else (x, 0)
@@ -407,7 +490,8 @@ class FFC_BN_ACT(_HipModule):
         if cl != self.ffc.in_cl or cg != self.ffc.in_cg:
             raise LamaError(f'FFC_BN_ACT expected ({self.ffc.in_cl},{self.ffc.in_cg}) local/global channels, got ({cl},{cg})')
         dst = torch.empty(self.out_shape(src.shape, extra_pad), device=src.device, dtype=torch.float32)
-        self.run(src, dst, self.make_scratch(src.shape, src.device), None, extra_pad)
+        with self._exec.range_scope(src, self.precision):
+            self.run(src, dst, self.make_scratch(src.shape, src.device), None, extra_pad)
         ocl, ocg = self.ffc.out_cl, self.ffc.out_cg
         return (dst[:, :ocl] if ocl else 0), (dst[:, ocl:] if ocg else 0)
 
@@ -435,7 +519,8 @@ class FFCResnetBlock(_HipModule):
         self._exec.check(x_l)
         src, cl, cg = _pair_buffer(x_l, x_g)
         tmp, dst = torch.empty_like(src), torch.empty_like(src)
-        self.run(src, tmp, dst, self.conv1.make_scratch(src.shape, src.device))
+        with self._exec.range_scope(src, self.precision):
+            self.run(src, tmp, dst, self.conv1.make_scratch(src.shape, src.device))
         return (dst[:, :cl], dst[:, cl:]) if cg else (dst, 0)
 
 
@@ -520,7 +605,7 @@ class ConvTranspose2dUp(nn.ConvTranspose2d, _HipModule):
             self._packed = (key, self._exec.lib.pack_conv_weight(self.weight.detach(), scale, stride=2, transposed=True,
                                                                   precision=self.precision), bias.contiguous())
         _, wp, bias = self._packed
-        self._exec.lib.conv2d(L.view(src), wp, L.view(dst), src.shape[0], 3, 2, 1, L.PAD_ZERO, True, bias, act,
+        self._exec.conv2d(L.view(src), wp, L.view(dst), src.shape[0], 3, 2, 1, L.PAD_ZERO, True, bias, act,
                               precision=self.precision, stream=self._exec.stream(src))
 
     def forward(self, x, bn=None, act=L.ACT_NONE):
@@ -528,7 +613,8 @@ class ConvTranspose2dUp(nn.ConvTranspose2d, _HipModule):
         x = x.contiguous()
         B, _, H, W = x.shape
         y = torch.empty(B, self.out_channels, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
-        self.run(x, y, bn, act)
+        with self._exec.range_scope(x, self.precision):
+            self.run(x, y, bn, act)
         return y
 
 
@@ -546,7 +632,7 @@ class Conv2dOut(nn.Conv2d, _HipModule):
             self._packed = (self._exec.lib.pack_conv_weight(self.weight.detach(), None, precision=self.precision),
                             self.bias.detach().float().contiguous())
         wp, bias = self._packed
-        self._exec.lib.conv2d(L.view(src), wp, L.view(dst), src.shape[0], self.kernel_size[0], 1, self.padding[0] + extra_pad,
+        self._exec.conv2d(L.view(src), wp, L.view(dst), src.shape[0], self.kernel_size[0], 1, self.padding[0] + extra_pad,
                               L.PAD_REFLECT, False, bias, act, precision=self.precision, stream=self._exec.stream(src))
 
     def forward(self, x, extra_pad=0, act=L.ACT_NONE):
@@ -555,7 +641,8 @@ class Conv2dOut(nn.Conv2d, _HipModule):
         B, _, H, W = x.shape
         k, p = self.kernel_size[0], self.padding[0] + extra_pad
         y = torch.empty(B, self.out_channels, H + 2 * p - k + 1, W + 2 * p - k + 1, device=x.device, dtype=torch.float32)
-        self.run(x, y, extra_pad, act)
+        with self._exec.range_scope(x, self.precision):
+            self.run(x, y, extra_pad, act)
         return y
 
 
@@ -565,6 +652,14 @@ class LayerSequence(nn.Sequential):
     separate layers: ReflectionPad2d -> conv, ConvTranspose2d -> BatchNorm2d -> ReLU, conv -> output act."""
 
     def forward(self, x):
+        hip = next((m for m in self if isinstance(m, _HipModule)), None)
+        first = x[0] if isinstance(x, tuple) else x
+        if hip is None or not torch.is_tensor(first):
+            return self._forward(x)
+        with hip._exec.range_scope(first, hip.precision):     # ONE range-flag read-back for the whole slice
+            return self._forward(x)
+
+    def _forward(self, x):
         layers = list(self)
         i, n = 0, len(layers)
         while i < n:
@@ -645,13 +740,20 @@ class FFCResNetGenerator(_HipModule):
         # with it about one layer run in a thousand produced a wrong FFT plane (a co-residency hazard between the FFT and conv
         # workgroups that is not understood yet -- tools/race_probe*.py reproduce it); the serial order is bit-reproducible.
         self.overlap_streams = False
-        self._plans = {}
+        # fp16-split range watch (lama_conv2d_args.range_flag): one 4-byte read-back per forward; when an activation beyond 65504
+        # (or a NaN) was met the forward is repeated with the 3-term bf16 split (fp32 exponent range) and the generator stays
+        # on it.  auto_fallback = False raises LamaRangeError instead.
+        self.auto_fallback = True
+        # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
+        # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
+        self.max_plans = 4
+        self._plans = collections.OrderedDict()
         super().train(False)
 
     # ------------------------------------------------------------------------------------------------
     def _invalidate(self):
         super()._invalidate()
-        self._plans = {}
+        self._plans = collections.OrderedDict()
 
     def _build_plan(self, shape, device):
         """Pre-allocate every activation buffer for an input shape and record the launch list."""
@@ -736,13 +838,32 @@ class FFCResNetGenerator(_HipModule):
                 lay.run(B(s), B(d), pad, act)
         return bufs[plan['out']]
 
+    def drop_plan(self, shape, device) -> None:
+        """Free the activation buffers / captured graph of one input shape (predict.py drops a bucket's plan when it is done)."""
+        self._plans.pop((tuple(shape), str(torch.device(device))), None)
+
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         self._exec.check(input)
         x = input.contiguous()
+        try:
+            with self._exec.range_scope(x, self.precision):
+                return self._forward(x)
+        except LamaRangeError as e:
+            if not self.auto_fallback or self.precision != L.PREC_F16X3:
+                raise
+            warnings.warn(f'lama_amd: {e}; switching this generator to the 3-term bf16 split (PREC_BF16X3)')
+            self.set_precision(L.PREC_BF16X3)
+            return self.forward(input)
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         key = (tuple(x.shape), str(x.device))
         plan = self._plans.get(key)
         if plan is None:
+            while len(self._plans) >= max(1, self.max_plans):
+                self._plans.popitem(last=False)
             plan = self._plans[key] = self._build_plan(x.shape, x.device)
+        else:
+            self._plans.move_to_end(key)
         if not (self.use_graph and x.is_cuda):
             return self._run_plan(plan, x).clone()
         if plan['graph'] is None:

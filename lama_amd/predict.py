@@ -40,17 +40,51 @@ DEFAULTS = {'model.checkpoint': 'best.ckpt', 'dataset.img_suffix': '.png', 'data
 # dataset glue (saicinpainting/evaluation/data.py:12-33,58-83)
 # ----------------------------------------------------------------------------------------------------------------
 
+# keys of configs/prediction/default.yaml this driver honours; anything else is rejected instead of silently ignored
+KNOWN_KEYS = set(DEFAULTS) | {'model.path', 'indir', 'outdir', 'device', 'dataset.kind', 'refine',
+                              'refiner.gpu_ids', 'refiner.modulo', 'refiner.n_iters', 'refiner.lr', 'refiner.min_side',
+                              'refiner.max_scales', 'refiner.px_budget'}
+REFINER_DEFAULTS = {'refiner.gpu_ids': '0,', 'refiner.modulo': 8, 'refiner.n_iters': 15, 'refiner.lr': 0.002, 'refiner.min_side': 512,
+                    'refiner.max_scales': 3, 'refiner.px_budget': 1800000}     # configs/prediction/default.yaml:16-24
+
+
+def _parse_value(v: str):
+    if v.lower() in ('true', 'false'):
+        return v.lower() == 'true'
+    try:
+        return int(v)
+    except ValueError:
+        pass
+    try:
+        return float(v)
+    except ValueError:
+        return v
+
+
 def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
-    """Hydra-style ``a.b=c`` overrides on top of configs/prediction/default.yaml's defaults."""
+    """Hydra-style ``a.b=c`` overrides on top of configs/prediction/default.yaml's defaults.  Unknown keys and options of the
+    reference this driver does not implement are errors (the reference would act on them; ignoring them silently would not be
+    a drop-in)."""
     cfg = dict(DEFAULTS)
+    cfg.update(REFINER_DEFAULTS)
     for a in argv:
         if '=' not in a:
             raise SystemExit(f'expected key=value, got {a!r}')
         k, v = a.split('=', 1)
-        cfg[k] = int(v) if v.lstrip('-').isdigit() else v
+        if k not in KNOWN_KEYS:
+            if k == 'dataset.scale_factor':
+                raise NotImplementedError('dataset.scale_factor (evaluation/data.py:74-77, cv2 resize) is not implemented')
+            raise SystemExit(f'unknown option {k!r}; known: {sorted(KNOWN_KEYS)}')
+        cfg[k] = _parse_value(v)
     for need in ('model.path', 'indir', 'outdir'):
         if need not in cfg:
             raise SystemExit(f'missing {need}=...')
+    if str(cfg.get('device', 'cuda')).split(':')[0] != 'cuda':
+        raise L.LamaError(f"device={cfg['device']}: lama_amd runs on an MI355X only (there is no CPU path)")
+    if cfg.get('dataset.kind', 'default') != 'default':
+        raise NotImplementedError(f"dataset.kind={cfg['dataset.kind']} (only the default InpaintingDataset of bin/predict.py)")
+    if cfg.get('out_key', 'inpainted') != 'inpainted':
+        raise NotImplementedError('out_key other than inpainted')
     return cfg
 
 
@@ -84,6 +118,8 @@ def load_item(mask_path: str, img_path: str, pad_mod: int):
     image = load_image(img_path, 'RGB')
     mask = load_image(mask_path, 'L')[None, ...]
     hw = image.shape[1:]
+    if tuple(mask.shape[1:]) != tuple(hw):
+        raise L.LamaError(f'{mask_path}: mask is {mask.shape[2]}x{mask.shape[1]} but {img_path} is {hw[1]}x{hw[0]}')
     if pad_mod and pad_mod > 1:
         image, mask = pad_img_to_modulo(image, pad_mod), pad_img_to_modulo(mask, pad_mod)
     return image, mask, hw
@@ -122,30 +158,47 @@ def _write_png(path: str, rgb: np.ndarray):
 def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[str, str]], indir: str, outdir: str, *,
             pad_mod: int = 8, batch_size: int = 8, out_ext: str = '.png', device='cuda', rank: int = 0, world: int = 1,
             dist=None, io_threads: int = 8) -> int:
-    """Run every (mask, image) pair through ``model`` and write the results (rank 0).  Returns the number of images written."""
+    """Run every (mask, image) pair through ``model`` and write the results (rank 0).  Returns the number of images written.
+
+    Host pipeline: the PNGs of round r + 1 are decoded / padded on the thread pool while round r computes, results are
+    written on the same pool; a partial last batch of a bucket is zero-padded to ``batch_size`` so that it replays the bucket's
+    captured plan instead of building (and capturing) a second one, and a bucket's plan is dropped when the bucket is done."""
     from PIL import Image
-    shapes = []
-    for m, _ in items:                       # padded shape from the PNG header only: every rank builds the same plan
-        with Image.open(m) as im:
+    shapes, sizes = [], []
+    for _, im_path in items:                 # padded shape from the IMAGE's PNG header only: every rank builds the same plan
+        with Image.open(im_path) as im:
             w, h = im.size
+        sizes.append((h, w))
         shapes.append((ceil_modulo(h, pad_mod), ceil_modulo(w, pad_mod)) if pad_mod and pad_mod > 1 else (h, w))
     rounds = plan_rounds(shapes, batch_size, world)
     lib = model.generator._exec.lib
-    pool = ThreadPoolExecutor(io_threads) if rank == 0 else None
+    pool = ThreadPoolExecutor(io_threads)
     futures, written = [], 0
-    for rd in rounds:
+
+    def submit_loads(rd):
+        return [pool.submit(load_item, *items[i], pad_mod) for i in rd['batches'][rank]]
+
+    pending = submit_loads(rounds[0]) if rounds else []
+    for ri, rd in enumerate(rounds):
         Hp, Wp = rd['shape']
         mine = rd['batches'][rank]
+        loaded = [f.result() for f in pending]
+        pending = submit_loads(rounds[ri + 1]) if ri + 1 < len(rounds) else []          # decode the next round under this one
         u8 = torch.zeros(batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
         if mine:
-            loaded = [load_item(*items[i], pad_mod) for i in mine]
-            image = torch.from_numpy(np.stack([x[0] for x in loaded])).to(device)
-            mask = torch.from_numpy(np.stack([x[1] for x in loaded])).to(device)
+            img_np = np.zeros((batch_size, 3, Hp, Wp), np.float32)
+            mask_np = np.zeros((batch_size, 1, Hp, Wp), np.float32)
+            for j, x in enumerate(loaded):
+                img_np[j], mask_np[j] = x[0], x[1]
+            image = torch.from_numpy(img_np).to(device)
+            mask = torch.from_numpy(mask_np).to(device)
             batch = dict(image=image, mask=(mask > 0) * 1)                          # bin/predict.py:84
             with torch.no_grad():
                 out = model(batch)['inpainted']                                    # bin/predict.py:85, out_key
             stream = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else 0
             lib.quantize_u8_hwc(L.view(out), u8, len(mine), Hp, Wp, stream)        # bin/predict.py:92 on the device
+        if ri + 1 == len(rounds) or rounds[ri + 1]['shape'] != rd['shape']:
+            model.generator.drop_plan((batch_size, 4, Hp, Wp), u8.device)           # bucket done: free its buffers / graph
         if world > 1:
             gathered = torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
             dist.all_gather_into_tensor(gathered, u8)                              # the only collective: output images
@@ -156,15 +209,13 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
             for r, idxs in enumerate(rd['batches']):
                 for j, i in enumerate(idxs):
                     mask_path = items[i][0]
-                    with Image.open(mask_path) as im:
-                        w, h = im.size
+                    h, w = sizes[i]
                     rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + out_ext      # bin/predict.py:69-72
                     futures.append(pool.submit(_write_png, os.path.join(outdir, rel), host[r * batch_size + j, :h, :w].copy()))
                     written += 1
     for f in futures:
         f.result()
-    if pool:
-        pool.shutdown()
+    pool.shutdown()
     return written
 
 
@@ -190,6 +241,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     model.generator.use_graph = True
     indir = cfg['indir'] if cfg['indir'].endswith(os.sep) else cfg['indir'] + os.sep               # bin/predict.py:63-64
     items = list_dataset(indir, cfg['dataset.img_suffix'])
+    if cfg.get('refine', False):
+        raise NotImplementedError('refine=True: use lama_amd.refinement.refine_predict (batch 1) -- see lama_amd/refinement.py')
     n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
                 out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist)
     if rank == 0:

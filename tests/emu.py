@@ -17,4 +17,4 @@ sys.path.insert(0, os.path.join(HERE, 'hipemu'))
 def emu_lib():
     import build_emu
     from lama_amd._lib import LamaLib
-    return LamaLib(build_emu.build())
+    return LamaLib(build_emu.build(), host_emulated=True)

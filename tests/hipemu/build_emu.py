@@ -35,7 +35,7 @@ def build(force=False):
     procs = []
     for s in srcs + [os.path.join(HERE, 'hipemu_runtime.cpp')]:
         o = os.path.join(OUT, os.path.basename(s) + '.o')
-        cmd = [cxx, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-Wno-unknown-attributes', '-Wno-ignored-attributes',
+        cmd = [cxx, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-DLAMA_PROFILING', '-Wno-unknown-attributes', '-Wno-ignored-attributes',
                '-I' + HERE, '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC, '-c', s, '-o', o]
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(o)

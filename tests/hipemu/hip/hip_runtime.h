@@ -110,6 +110,10 @@ inline uint32_t (*exchange(const uint32_t* mine, int n))[16] {
 extern __attribute__((aligned(16))) char lama_smem[];
 
 static inline void __syncthreads() { hipemu::block_barrier(); }
+// fibers of a block run one at a time on one host thread: a plain read-modify-write is atomic here
+static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}

@@ -135,3 +135,39 @@ def test_product_path_has_no_cpu_fallback():
         F.SpectralTransform(8, 8, enable_lfu=True)
     with pytest.raises(NotImplementedError):
         gen.train()
+
+
+def test_f16_split_overflow_falls_back_to_bf16x3():
+    """ADVICE r1 / VERDICT weak #4: |x| > 65504 must not silently return inf / garbage from the default f16 split.  The kernels
+    raise lama_conv2d_args.range_flag, the generator re-runs on the 3-term bf16 split (and stays there); with auto_fallback off
+    the forward raises LamaRangeError; stand-alone layers raise as well."""
+    from lama_amd import _lib as L
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = O.make_synthetic_state_dict(cfg, seed=5, calib_hw=32)
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen.set_exec(F._Exec(emu_lib()))
+    assert gen.precision == L.PREC_F16X3
+    batch = O.make_synthetic_batch(1, 64, 64, seed=2)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    y0 = gen(x)                                               # in range: stays on the f16 split
+    assert gen.precision == L.PREC_F16X3
+    xb = x.clone()
+    xb[0, 1, 20:24, 30:34] = 3.0e5                            # far outside the fp16 range
+    with torch.no_grad():
+        ref = O.generator_forward(xb, sd, cfg)
+    gen.auto_fallback = False
+    with pytest.raises(L.LamaRangeError):
+        gen(xb)
+    assert gen.precision == L.PREC_F16X3
+    with pytest.raises(L.LamaRangeError):
+        gen.model[1](torch.nn.functional.pad(xb, (3, 3, 3, 3), mode='reflect'))      # stand-alone layer: raises, no fallback
+    gen.auto_fallback = True
+    with pytest.warns(UserWarning, match='bf16'):
+        yb = gen(xb)
+    assert gen.precision == L.PREC_BF16X3 and all(m.precision == L.PREC_BF16X3 for m in gen.modules() if isinstance(m, F._HipModule))
+    # (a 3e5 input carries 16 mantissa bits on the bf16 split: absolute error ~5 near the spike, fp32-class everywhere else)
+    err = (yb - ref).abs()
+    assert torch.isfinite(yb).all() and float(err.mean()) < 1e-3 and float((err < 1e-3).float().mean()) > 0.97, (float(err.mean()), float((err < 1e-3).float().mean()))
+    y1 = gen(x)                                               # and the in-range input still matches on the bf16 split
+    assert float((y1 - y0).abs().max()) < 1e-3, float((y1 - y0).abs().max())

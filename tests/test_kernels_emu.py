@@ -254,3 +254,26 @@ def test_c_abi_rejects_bad_arguments():
         lib.rfft2(L.view(x), L.view(torch.zeros(1, 8, 8, 4)), 1)      # wrong spectrum width
     with pytest.raises(L.LamaError):
         lib.rfft2(L.view(torch.zeros(1, 4, 10, 12)), L.view(torch.zeros(1, 8, 10, 7)), 1, None)   # missing workspace
+
+
+def test_f16_split_range_watch_emulated():
+    """lama_conv2d_args.range_flag: an activation beyond 65504 (or a NaN) met while the f16 split is applied raises the flag;
+    in-range inputs and the other precisions leave it alone (conv_split3.inc cb_split2 / cb_range_report)."""
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(31)
+    for (cin, cout, k, H, W) in [(8, 16, 3, 8, 8), (64, 96, 3, 5, 6), (192, 96, 1, 4, 16), (4, 64, 7, 9, 40), (64, 3, 7, 10, 40)]:
+        x = torch.randn(1, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) * 0.1
+        y = torch.zeros(1, cout, H, W)
+        for prec in (L.PREC_F16X3, L.PREC_BF16X3):
+            wp = lib.pack_conv_weight(w, None, precision=prec)
+            for big, want in ((None, 0), (7.0e4, 1), (-1.0e5, 1), (float('nan'), 1), (6.5e4, 0)):
+                xx = x.clone()
+                if big is not None:
+                    xx[0, cin // 2, H // 2, W // 3] = big
+                flag = torch.zeros(1, dtype=torch.int32)
+                lib.conv2d(L.view(xx), wp, L.view(y), 1, k, 1, k // 2, L.PAD_REFLECT, False, None, L.ACT_NONE, precision=prec, range_flag=flag)
+                assert int(flag) == (want if prec == L.PREC_F16X3 else 0), (cin, cout, k, prec, big, int(flag))
+    with pytest.raises(L.LamaRangeError):                                  # weights are checked by the host at pack time
+        lib.pack_conv_weight(torch.full((8, 8, 1, 1), 7.0e4), None, precision=L.PREC_F16X3)
+    lib.pack_conv_weight(torch.full((8, 8, 1, 1), 7.0e4), None, precision=L.PREC_BF16X3)

@@ -15,8 +15,26 @@ from tests.test_kernels_emu import CONV_CASES, CONV_TOL, FFT_SIZES, PREC_IDS, PR
 
 @pytest.fixture(scope='module')
 def lib():
+    """The PRODUCT library under its production kernel selection: liblama_hip.so reads no environment variable, so the
+    LAMA_*=2 overrides tests/emu.py sets for the emulator (and for ``lib_forced`` below) do not reach it."""
     assert torch.cuda.is_available(), 'these tests need the MI355X'
     return L.get_lib()          # raises if liblama_hip.so was not built: no fallback
+
+
+@pytest.fixture(scope='module')
+def lib_forced():
+    """The -DLAMA_PROFILING build of the same sources with the specialised kernels forced at any launch size (LAMA_GEMM_WS /
+    LAMA_CW_1X1 / LAMA_STEM_WS / LAMA_HEAD_WS = 2, set by tests/emu.py): the ragged-edge cases of CONV_CASES reach the
+    persistent GEMM / stem / head / full-M kernels on hardware although production would not pick them at these sizes."""
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from lama_amd import build as B
+    assert os.environ.get('LAMA_GEMM_WS') == '2' and os.environ.get('LAMA_STEM_WS') == '2'
+    return L.LamaLib(B.LIB_PROF)
+
+
+@pytest.fixture(params=['production', 'forced'])
+def anylib(request, lib, lib_forced):
+    return lib if request.param == 'production' else lib_forced
 
 
 DEV = 'cuda'
@@ -24,7 +42,8 @@ DEV = 'cuda'
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
 @pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
-def test_conv2d(lib, case, prec):
+def test_conv2d(anylib, case, prec):
+    lib = anylib
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)
@@ -66,6 +85,41 @@ def test_conv2d_big_tiles(lib, shape, prec):
     ref = _conv_ref(x, w, 1, k // 2, True, False, bias, 1, None)
     y = torch.empty(B, cout, H, W, device=DEV)
     xd, bd = x.to(DEV), bias.to(DEV)             # keep the device copies alive until the kernel ran
+    wp = lib.pack_conv_weight(w.to(DEV), None, precision=prec)
+    lib.conv2d(L.view(xd), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bd, L.ACT_RELU, precision=prec,
+               stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.allclose(y.cpu(), ref, atol=3e-4, rtol=1e-4), float((y.cpu() - ref).abs().max())
+
+
+# Shapes on BOTH sides of every size threshold of the production kernel selection (conv_wreg_host.inc): the specialised kernel
+# just takes the launch / the launch just falls through to the next kernel in line.
+#   gw_try_launch   (persistent pointwise GEMM): C in {192, 384}, rows % 96 == 0, 32-pixel tiles x row groups >= 64
+#   cw_try_launch   (full-M 1x1 workgroups):     128-pixel tiles >= 96  (cin % 64 == 0, rows = 384 / 192, not taken by gw)
+#   stem_try_launch (7x7, cin <= 4):             B * H * ceil(W / 32) >= 4096
+#   head_try_launch (7x7, cin 64, cout <= 4):    B * ceil(W / 26) * H >= 8192
+THRESHOLD_SHAPES = [
+    # B, cin, cout, k, H, W
+    (2, 192, 96, 1, 32, 32), (2, 192, 96, 1, 31, 32),          # gw: 64 tiles x 1 group on / 62 off (-> 128-row wreg tiles refused: generic)
+    (1, 384, 192, 1, 32, 32), (1, 384, 192, 1, 32, 31),        # gw: 32 tiles x 2 groups on / 31 x 2 off (-> wreg 6 x 2 or generic)
+    (3, 128, 384, 1, 64, 64), (2, 128, 384, 1, 64, 95),        # cw full-M 12 x 1: 3 * 32 = 96 tiles on, 2 * 48 = 96 (ragged) on
+    (1, 128, 384, 1, 64, 95), (1, 256, 192, 1, 95, 128),       # cw: 48 tiles off (-> 128-row wreg tiles) / 95 tiles, 192 rows off (-> LDS-staged)
+    (2, 4, 64, 7, 64, 1024), (2, 4, 64, 7, 63, 1024),          # stem: 4096 on / 4032 off (LDS-staged MODE 1 kernel)
+    (2, 64, 3, 7, 256, 416), (2, 64, 3, 7, 255, 416),          # head: 8192 on / 8160 off (LDS-staged MODE 2 kernel)
+]
+
+
+@pytest.mark.parametrize('prec', [L.PREC_F16X3, L.PREC_BF16X3], ids=['f16x3', 'bf16x3'])
+@pytest.mark.parametrize('shape', THRESHOLD_SHAPES, ids=lambda s: 'x'.join(map(str, s)))
+def test_conv2d_selection_thresholds(lib, shape, prec):
+    B, cin, cout, k, H, W = shape
+    g = torch.Generator().manual_seed(44)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = _conv_ref(x, w, 1, k // 2, True, False, bias, 1, None)
+    y = torch.empty(B, cout, H, W, device=DEV)
+    xd, bd = x.to(DEV), bias.to(DEV)
     wp = lib.pack_conv_weight(w.to(DEV), None, precision=prec)
     lib.conv2d(L.view(xd), wp, L.view(y), B, k, 1, k // 2, L.PAD_REFLECT, False, bd, L.ACT_RELU, precision=prec,
                stream=torch.cuda.current_stream().cuda_stream)
@@ -139,7 +193,8 @@ def test_rfft2_irfft2(lib, hw):
 
 
 @pytest.mark.parametrize('n_seq', [(64, 1), (64, 2), (64, 3), (128, 2), (128, 3)], ids=lambda s: f'{s[0]}seq{s[1]}')
-def test_fft_sequential_planes(lib, n_seq, monkeypatch):
+def test_fft_sequential_planes(lib_forced, n_seq, monkeypatch):
+    lib = lib_forced      # LAMA_FFT_SEQ / LAMA_FFT_INPLACE exist in the profiling build only
     """Sized one-plane FFT kernels walking LAMA_FFT_SEQ consecutive planes per workgroup (next plane prefetched)."""
     n, seq = n_seq
     monkeypatch.setenv('LAMA_FFT_SEQ', str(seq))
@@ -205,3 +260,36 @@ def test_elementwise(lib):
     lib.quantize_u8_hwc(L.view(srcd), u8, B, 37, 50, st)
     ref = np.clip(src.permute(0, 2, 3, 1).numpy()[:, :37, :50] * 255, 0, 255).astype('uint8')
     assert np.array_equal(u8.cpu().numpy(), ref)
+
+
+def test_f16_split_range_watch(lib):
+    """the default f16 split must not return inf / garbage silently.  A FourierUnit input whose DC bin
+    leaves the fp16 range (|DC| = sqrt(h*w) * mean = 64 * 2000 > 65504) raises lama_fourier_unit_fwd's range flag on the f16
+    split; the bf16 split takes the same input (flag untouched) and matches the oracle to its 16 mantissa bits."""
+    from oracle import lama_oracle as O
+    g = torch.Generator().manual_seed(6)
+    B, Cn, h, w = 2, 192, 64, 64
+    x = torch.randn(B, Cn, h, w, generator=g)
+    sd = {'fu.conv_layer.weight': torch.randn(2 * Cn, 2 * Cn, 1, 1, generator=g) / (2 * Cn) ** 0.5,
+          'fu.bn.weight': torch.rand(2 * Cn, generator=g) + 0.5, 'fu.bn.bias': torch.randn(2 * Cn, generator=g) * 0.2,
+          'fu.bn.running_mean': torch.randn(2 * Cn, generator=g) * 0.1, 'fu.bn.running_var': torch.rand(2 * Cn, generator=g) + 0.5}
+    scale = sd['fu.bn.weight'] / torch.sqrt(sd['fu.bn.running_var'] + 1e-5)
+    shift = (sd['fu.bn.bias'] - sd['fu.bn.running_mean'] * scale).to(DEV)
+    ws = torch.zeros(lib.fourier_unit_workspace_bytes(B, Cn, h, w) // 4 + 1, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    xbig = x.clone()
+    xbig[1, 7] += 2000.0                                    # DC of that plane = 64 * 2000 = 128000
+    for prec in (L.PREC_F16X3, L.PREC_BF16X3):
+        wp = lib.pack_conv_weight(sd['fu.conv_layer.weight'].to(DEV), scale.to(DEV), precision=prec)
+        for inp, overflow in ((x, False), (xbig, True)):
+            flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+            xd = inp.to(DEV)
+            y = torch.zeros_like(xd)
+            lib.fourier_unit(L.view(xd), wp, shift, L.view(y), B, True, ws, precision=prec, stream=st, range_flag=flag)
+            torch.cuda.synchronize()
+            assert int(flag.item()) == (1 if (overflow and prec == L.PREC_F16X3) else 0), (prec, overflow)
+            if not (overflow and prec == L.PREC_F16X3):
+                with torch.no_grad():
+                    ref = inp + O.fourier_unit(inp, sd, 'fu')
+                tol = 1e-4 if not overflow else 0.5          # 128000 * 2^-17 per product on the bf16 split
+                assert float((y.cpu() - ref).abs().max()) < tol
