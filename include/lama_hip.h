@@ -138,6 +138,47 @@ int lama_affine_act_fwd(void* stream, const lama_tensor* x, const float* scale, 
 /* Stand-alone nn.ReflectionPad2d(pad) (ffc.py:314,360); fused into the 7x7 convs on the normal path. */
 int lama_reflect_pad_fwd(void* stream, const lama_tensor* x, int32_t pad, const lama_tensor* y, int32_t batch);
 
+/* ------------------------------------------------------------------------------------------------
+ * Feature refinement (saicinpainting/evaluation/refinement.py, `refine=True` of bin/predict.py:75-79): what is
+ * not a convolution / FFT.  The dgrad of every conv / FourierUnit of generator.model[first_resblock:] reuses
+ * lama_conv2d_fwd / lama_rfft2_fwd / lama_irfft2_fwd with transposed, flipped packed weights (lama_amd/backward.py);
+ * autograd (refinement.py:163 loss.backward()) is replaced by that explicit reverse pass.
+ * ------------------------------------------------------------------------------------------------ */
+/* gout = g * act'(y) with the derivative expressed through the layer OUTPUT y: ReLU -> [y > 0], sigmoid -> y (1 - y),
+ * tanh -> 1 - y^2, none -> 1.  Backward of the ReLU / Sigmoid of ffc.py:253-254,354,363 and of FourierUnit's ReLU (ffc.py:101). */
+int lama_act_bwd(void* stream, const lama_tensor* g, const lama_tensor* y, int32_t act, const lama_tensor* gout, int32_t batch);
+/* out = a + b: gradient joins of the residual / two-branch structure (ffc.py:161,220-223,288) */
+int lama_add_fwd(void* stream, const lama_tensor* a, const lama_tensor* b, const lama_tensor* out, int32_t batch);
+/* adjoint of nn.ReflectionPad2d(pad) / padding_mode='reflect' (ffc.py:188-196,314,360): gp [B,C,H+2p,W+2p] -> g [B,C,H,W]
+ * (+ addend, optional): every padded position is added onto the input pixel it mirrors. */
+int lama_reflect_pad_bwd(void* stream, const lama_tensor* gp, const lama_tensor* addend, int32_t pad, const lama_tensor* g,
+                         int32_t batch);
+/* kornia.filters.gaussian_blur2d(x, (5,5), (1.0,1.0)) [border reflect] of the top-left crop [0:y.H, 0:y.W] of x
+ * (refinement.py:24,52,149), and its adjoint (gx is zero outside the crop). */
+int lama_gauss5_fwd(void* stream, const lama_tensor* x, const lama_tensor* y, int32_t batch);
+int lama_gauss5_bwd(void* stream, const lama_tensor* gy, const lama_tensor* gx, int32_t batch);
+/* F.interpolate(x, size=(y.H, y.W), mode='bilinear', align_corners=False) (refinement.py:25,53,55,200-201) and its adjoint. */
+int lama_bilinear_fwd(void* stream, const lama_tensor* x, const lama_tensor* y, int32_t batch);
+int lama_bilinear_bwd(void* stream, const lama_tensor* gy, const lama_tensor* gx, int32_t batch);
+/* y = x >= thr ? 1 : 0  (mask[mask >= eps] = 1; mask[mask < eps] = 0: refinement.py:57-62,70-71,300-301) */
+int lama_threshold_fwd(void* stream, const lama_tensor* x, float thr, const lama_tensor* y, int32_t batch);
+/* kornia.morphology.erosion(x, se) with a flat structuring element se [kh,kw] (device floats, non-zero = member; origin =
+ * centre; geodesic border: positions outside the image never lower the minimum), refinement.py:68 with the 15x15 ellipse. */
+int lama_erode_fwd(void* stream, const lama_tensor* x, const float* se, int32_t kh, int32_t kw, float max_val, const lama_tensor* y,
+                   int32_t batch);
+/* Masked L1 terms of refinement.py:75-84 over the elements with mask < thr (select_ge = 0) or mask >= thr (select_ge = 1); a
+ * 1-channel mask is broadcast over pred's channels (mask.repeat(1,3,1,1)).
+ *   fwd: accum[0] += sum |pred - target|, accum[1] += number of selected elements   (two device doubles, zeroed by the caller)
+ *   bwd: g = (accumulate ? g : 0) + scale * sign(pred - target) on the selected elements  (d mean|.| / d pred: scale = 1 / count) */
+int lama_l1_masked_fwd(void* stream, const lama_tensor* pred, const lama_tensor* target, const lama_tensor* mask, float thr,
+                       int32_t select_ge, double* accum, int32_t batch);
+int lama_l1_masked_bwd(void* stream, const lama_tensor* pred, const lama_tensor* target, const lama_tensor* mask, float thr,
+                       int32_t select_ge, float scale, int32_t accumulate, const lama_tensor* g, int32_t batch);
+/* one torch.optim.Adam step (refinement.py:134,165: betas, eps as given, no weight decay / amsgrad) on a flat fp32 buffer;
+ * step = 1, 2, ... */
+int lama_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                   float beta2, float eps, int32_t step);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,6 +101,18 @@ class LamaLib:
         L.lama_affine_act_fwd.argtypes = [vp, T, vp, vp, i32, T, i32]
         L.lama_reflect_pad_fwd.restype = C.c_int
         L.lama_reflect_pad_fwd.argtypes = [vp, T, i32, T, i32]
+        f32, dp = C.c_float, C.POINTER(C.c_double)
+        for name, args in (('lama_act_bwd', [vp, T, T, i32, T, i32]), ('lama_add_fwd', [vp, T, T, T, i32]),
+                           ('lama_reflect_pad_bwd', [vp, T, T, i32, T, i32]), ('lama_gauss5_fwd', [vp, T, T, i32]),
+                           ('lama_gauss5_bwd', [vp, T, T, i32]), ('lama_bilinear_fwd', [vp, T, T, i32]),
+                           ('lama_bilinear_bwd', [vp, T, T, i32]), ('lama_threshold_fwd', [vp, T, f32, T, i32]),
+                           ('lama_erode_fwd', [vp, T, vp, i32, i32, f32, T, i32]),
+                           ('lama_l1_masked_fwd', [vp, T, T, T, f32, i32, vp, i32]),
+                           ('lama_l1_masked_bwd', [vp, T, T, T, f32, i32, f32, i32, T, i32]),
+                           ('lama_adam_step', [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32])):
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = C.c_int, args
+        del dp
         if L.lama_version() != ABI_VERSION:
             raise LamaError(f'{path}: ABI version {L.lama_version()} != {ABI_VERSION}')
 
@@ -206,6 +218,57 @@ class LamaLib:
 
     def reflect_pad(self, x: Tensor4, pad: int, y: Tensor4, batch: int, stream: int = 0):
         self.check(self._l.lama_reflect_pad_fwd(stream, C.byref(x), pad, C.byref(y), batch), 'lama_reflect_pad_fwd')
+
+
+    # -- refinement (include/lama_hip.h, last section) --------------------------------------------
+    def act_bwd(self, g: Tensor4, y: Tensor4, act: int, gout: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_act_bwd(stream, C.byref(g), C.byref(y), act, C.byref(gout), batch), 'lama_act_bwd')
+
+    def add(self, a: Tensor4, b: Tensor4, out: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_add_fwd(stream, C.byref(a), C.byref(b), C.byref(out), batch), 'lama_add_fwd')
+
+    def reflect_pad_bwd(self, gp: Tensor4, addend: Optional[Tensor4], pad: int, g: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_reflect_pad_bwd(stream, C.byref(gp), None if addend is None else C.byref(addend), pad, C.byref(g), batch),
+                   'lama_reflect_pad_bwd')
+
+    def gauss5(self, x: Tensor4, y: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_gauss5_fwd(stream, C.byref(x), C.byref(y), batch), 'lama_gauss5_fwd')
+
+    def gauss5_bwd(self, gy: Tensor4, gx: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_gauss5_bwd(stream, C.byref(gy), C.byref(gx), batch), 'lama_gauss5_bwd')
+
+    def bilinear(self, x: Tensor4, y: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_bilinear_fwd(stream, C.byref(x), C.byref(y), batch), 'lama_bilinear_fwd')
+
+    def bilinear_bwd(self, gy: Tensor4, gx: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_bilinear_bwd(stream, C.byref(gy), C.byref(gx), batch), 'lama_bilinear_bwd')
+
+    def threshold(self, x: Tensor4, thr: float, y: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_threshold_fwd(stream, C.byref(x), thr, C.byref(y), batch), 'lama_threshold_fwd')
+
+    def erode(self, x: Tensor4, se: torch.Tensor, y: Tensor4, batch: int, max_val: float = 1e4, stream: int = 0):
+        kh, kw = se.shape
+        self.check(self._l.lama_erode_fwd(stream, C.byref(x), se.data_ptr(), kh, kw, max_val, C.byref(y), batch), 'lama_erode_fwd')
+
+    def l1_masked(self, pred: Tensor4, target: Tensor4, mask: Tensor4, thr: float, select_ge: bool, accum: torch.Tensor, batch: int,
+                  stream: int = 0):
+        assert accum.dtype == torch.float64 and accum.numel() >= 2
+        self.check(self._l.lama_l1_masked_fwd(stream, C.byref(pred), C.byref(target), C.byref(mask), thr, int(select_ge), accum.data_ptr(),
+                                              batch), 'lama_l1_masked_fwd')
+
+    def l1_masked_bwd(self, pred: Tensor4, target: Tensor4, mask: Tensor4, thr: float, select_ge: bool, scale: float, accumulate: bool,
+                      g: Tensor4, batch: int, stream: int = 0):
+        self.check(self._l.lama_l1_masked_bwd(stream, C.byref(pred), C.byref(target), C.byref(mask), thr, int(select_ge), scale,
+                                              int(accumulate), C.byref(g), batch), 'lama_l1_masked_bwd')
+
+    def adam_step(self, param: torch.Tensor, grad: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, lr: float, step: int,
+                  beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, stream: int = 0):
+        n = param.numel()
+        for t_ in (param, grad, exp_avg, exp_avg_sq):
+            if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.numel() != n:
+                raise LamaError('adam_step: contiguous fp32 tensors of one size expected')
+        self.check(self._l.lama_adam_step(stream, param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), n, lr,
+                                          beta1, beta2, eps, step), 'lama_adam_step')
 
 
 _LIB: Optional[LamaLib] = None

@@ -114,10 +114,18 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
 static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
+// v_cmp_class_f32: bit 0 sNaN, 1 qNaN, 2 -inf, 9 +inf (the only classes the kernels test)
+static inline bool __builtin_amdgcn_classf(float v, int mask) {
+    if (v != v) return (mask & 0x3) != 0;
+    if (v == -__builtin_inff()) return (mask & 0x4) != 0;
+    if (v == __builtin_inff()) return (mask & 0x200) != 0;
+    return false;
+}
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
 
