@@ -23,6 +23,15 @@ LIB_PROF = os.path.join(LIBDIR, 'liblama_hip_prof.so')
 SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'fft.hip', 'elementwise.hip', 'refine.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'),
            os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
+# Every translation unit is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
+# Measured on MI355X / ROCm 7.2 (tools/race_probe5-9.py): a v_pk_*_f32 with an op_sel half-swizzle returns wrong
+# results while a wave of ANOTHER kernel executes MFMA instructions on the same SIMD (an inline-asm probe of that one instruction
+# fails 60 / 60 next to a bare MFMA loop, the plain forms pass).  hipcc's SLP vectoriser emits thousands of them for the float2
+# butterflies of the FFT kernels, which therefore produced wrong planes in up to 99 % of the runs next to a convolution on a second
+# stream -- and 0 of 100 000 without them.  Costs nothing measurable (bench: 555 vs 559 images/s, inside the run-to-run noise).
+NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
+PROF_ONLY_SOURCES = ['debug_probes.hip']      # the probes of tools/race_probe8/9.py: built WITH packed fp32, on purpose
+PER_SOURCE_FLAGS = {}                        # filled below: NO_PACKED_FP32 for every product source
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
                '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]
 
@@ -39,22 +48,26 @@ def _digest(paths, extra_flags=()) -> str:
     for p in paths:
         with open(p, 'rb') as f:
             h.update(f.read())
-    h.update(' '.join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
+    h.update(' '.join(list(HIPCC_FLAGS) + list(extra_flags) + [repr(sorted(PER_SOURCE_FLAGS.items()))]).encode())
     return h.hexdigest()
 
 
 def _compile(args):
     src, obj, hipcc, extra = args
-    cmd = [hipcc, *HIPCC_FLAGS, *extra, '-c', src, '-o', obj]
+    cmd = [hipcc, *HIPCC_FLAGS, *extra, *PER_SOURCE_FLAGS.get(os.path.basename(src), []), '-c', src, '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
     return obj
 
 
-def _build_one(lib: str, extra_flags, force: bool, verbose: bool) -> str:
+for _s in ('conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'fft.hip', 'elementwise.hip', 'refine.hip'):
+    PER_SOURCE_FLAGS[_s] = NO_PACKED_FP32
+
+
+def _build_one(lib: str, extra_flags, force: bool, verbose: bool, extra_sources=()) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    srcs = [os.path.join(CSRC, s) for s in list(SOURCES) + list(extra_sources)]
     tag = os.path.splitext(os.path.basename(lib))[0]
     stamp = os.path.join(LIBDIR, tag + '.sha256')
     dig = _digest(srcs + HEADERS, extra_flags)
@@ -84,7 +97,7 @@ def build(force: bool = False, verbose: bool = True, profiling: bool = True) -> 
         return _build_one(LIB, [], force, verbose)
     with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
         f1 = ex.submit(_build_one, LIB, [], force, verbose)
-        f2 = ex.submit(_build_one, LIB_PROF, ['-DLAMA_PROFILING'], force, verbose)
+        f2 = ex.submit(_build_one, LIB_PROF, ['-DLAMA_PROFILING'], force, verbose, PROF_ONLY_SOURCES)
         f2.result()
         return f1.result()
 

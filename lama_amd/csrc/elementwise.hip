@@ -259,3 +259,4 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
     if (rc) return rc;
     return lama_irfft2_fwd(stream, &s2, add_input ? x : nullptr, y, batch, fws, fws_bytes);
 }
+

@@ -20,7 +20,7 @@ def _cxx():
 
 def build(force=False):
     os.makedirs(OUT, exist_ok=True)
-    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+    srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip') and f != 'debug_probes.hip')
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'),
                    os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h'),
                    os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.join(HERE, 'hipemu_runtime.cpp')]

@@ -11,7 +11,7 @@ model.load_state_dict(sdg, strict=True); model.freeze().cuda()
 for overlap in (False, True):
     for graph in (False, True):
         model.generator.overlap_streams = overlap
-        model.generator._plans = {}
+        model.generator._plans.clear()
         model.generator.use_graph = graph
         outs = []
         for i in range(6):
