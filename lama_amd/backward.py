@@ -165,6 +165,7 @@ class RearPass:
         self._plan = None
         self._bw_up: Dict[int, torch.Tensor] = {}
         self._bw_head = None
+        self.debug: Optional[dict] = None      # tests: receives clones of the gradient at every stage boundary of backward()
 
     # ---------------------------------------------------------------------------------------------------------------
     def _build(self, z: torch.Tensor):
@@ -241,6 +242,8 @@ class RearPass:
         lib.conv2d(L.view(hd['g1']), self._bw_head, L.view(hd['gp']), B, k, 1, k - 1, L.PAD_ZERO, False, None, L.ACT_NONE, precision=prec, stream=st)
         g = p['ups'][-1]['g'] if self.ups else p['gst'][0]
         lib.reflect_pad_bwd(L.view(hd['gp']), None, pad, L.view(g), B, st)
+        if self.debug is not None:
+            self.debug['head_in'] = g.clone()
         for ui in range(len(self.ups) - 1, -1, -1):
             up, bn = self.ups[ui]
             ub = p['ups'][ui]
@@ -249,6 +252,8 @@ class RearPass:
             lib.conv2d(L.view(ub['g']), self._up_bwd_weight(ui, up, bn), L.view(dst), B, 3, 2, 1, L.PAD_ZERO, False, None, L.ACT_NONE,
                        precision=prec, stream=st)
             g = dst
+            if self.debug is not None:
+                self.debug[f'up{ui}_in'] = g.clone()
         # g = d loss / d (state after the last block); walk the blocks backwards
         gi = 0
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -259,4 +264,6 @@ class RearPass:
             t1.backward(ga, gb, tp['c1'], p['sh'])             # d / d (block input) through the two layers
             lib.add(L.view(gb), L.view(g), L.view(ga), B, st)  # + the identity path (ffc.py:288)
             g, gi = ga, (gi + 1) % 3
+            if self.debug is not None:
+                self.debug[f'block{bi}_in'] = g.clone()
         return g

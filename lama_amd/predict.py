@@ -219,6 +219,35 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
     return written
 
 
+def predict_refine(model, items: List[Tuple[str, str]], indir: str, outdir: str, cfg: dict, *, device='cuda', rank: int = 0,
+                   world: int = 1) -> int:
+    """``refine=True`` (bin/predict.py:75-81): one image at a time through lama_amd.refinement.refine_predict.  Each image's
+    optimisation is sequential, so the ranks are plain replicas: rank r takes items r, r + world, ... and writes its own results
+    (no collective on this path)."""
+    from .refinement import refine_predict
+    pad_mod = int(cfg['dataset.pad_out_to_modulo'])
+    pool = ThreadPoolExecutor(4)
+    futures, written = [], 0
+    for i in range(rank, len(items), world):
+        mask_path, img_path = items[i]
+        image, mask, (h, w) = load_item(mask_path, img_path, pad_mod)
+        batch = dict(image=torch.from_numpy(image)[None].to(device), mask=torch.from_numpy(mask)[None].to(device),
+                     unpad_to_size=[torch.tensor([h]), torch.tensor([w])])
+        batch['mask'] = ((batch['mask'] > 0) * 1).float()                                                  # bin/predict.py:84
+        cur_res = refine_predict(batch, model, gpu_ids=str(cfg['refiner.gpu_ids']), modulo=int(cfg['refiner.modulo']),
+                                 n_iters=int(cfg['refiner.n_iters']), lr=float(cfg['refiner.lr']), min_side=int(cfg['refiner.min_side']),
+                                 max_scales=int(cfg['refiner.max_scales']), px_budget=int(cfg['refiner.px_budget']))
+        res = cur_res[0].permute(1, 2, 0).numpy()                                                          # bin/predict.py:80
+        u8 = np.clip(res * 255, 0, 255).astype('uint8')                                                    # bin/predict.py:92
+        rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + cfg['out_ext']
+        futures.append(pool.submit(_write_png, os.path.join(outdir, rel), u8))
+        written += 1
+    for f in futures:
+        f.result()
+    pool.shutdown()
+    return written
+
+
 def main(argv: Optional[Sequence[str]] = None) -> int:
     cfg = parse_overrides(sys.argv[1:] if argv is None else argv)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -241,8 +270,13 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     model.generator.use_graph = True
     indir = cfg['indir'] if cfg['indir'].endswith(os.sep) else cfg['indir'] + os.sep               # bin/predict.py:63-64
     items = list_dataset(indir, cfg['dataset.img_suffix'])
-    if cfg.get('refine', False):
-        raise NotImplementedError('refine=True: use lama_amd.refinement.refine_predict (batch 1) -- see lama_amd/refinement.py')
+    if cfg.get('refine', False):                                                                    # bin/predict.py:75-81
+        n = predict_refine(model, items, indir, cfg['outdir'], cfg, device=device, rank=rank, world=world)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        print(f'rank {rank}: wrote {n} refined images to {cfg["outdir"]}')
+        return 0
     n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
                 out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist)
     if rank == 0:

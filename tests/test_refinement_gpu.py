@@ -1,0 +1,89 @@
+"""GPU parity of the refinement path (BASELINE configs[4], saicinpainting/evaluation/refinement.py) against the CPU oracle:
+gradients of the explicit reverse pass at big-lama's channel counts against torch autograd, and refine_predict end to end."""
+import numpy as np
+import pytest
+import torch
+
+from lama_amd import _lib as L
+from lama_amd import ffc as F
+from lama_amd import refinement as RF
+from lama_amd import trainers
+from lama_amd.backward import RearPass
+from lama_amd.modules import make_generator
+from oracle import lama_oracle as O
+from oracle import refine_oracle as R
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def big2():
+    """big-lama channel counts (512-channel bottleneck, 128 | 384 split, 192-channel spectral branch), two resnet blocks."""
+    cfg = dict(O.BIG_LAMA)
+    cfg['n_blocks'] = 2
+    sd = O.make_synthetic_state_dict(cfg, seed=2, calib_hw=64)
+    return cfg, sd
+
+
+@pytest.mark.parametrize('res', [64, 256], ids=['64px_strict', '256px_planes32'])
+@pytest.mark.parametrize('fwd_prec,bwd_prec,tol', [(L.PREC_F32, L.PREC_F32, 5e-5), (L.PREC_F16X3, L.PREC_BF16X3, 3e-3)],
+                         ids=['f32', 'f16x3_fwd_bf16x3_bwd'])
+def test_rear_gradients_full_channel_count(big2, fwd_prec, bwd_prec, tol, res):
+    """d loss / d (z1, z2) through two FFCResnetBlocks (incl. the FourierUnit adjoints), the three fused ConvTranspose2d + BN + ReLU
+    and the 7x7 head + sigmoid at big-lama's channel counts, against torch autograd through the oracle.
+
+    ReLU' is discontinuous: a pre-activation within rounding distance of 0 gets mask 1 on one side and 0 on the other (two valid
+    fp32 evaluations), and each such flip changes the gradient by 100 % of one element, which the dgrad convs spread over a
+    neighbourhood and the FourierUnit adjoint over a whole plane.  At 64 x 64 (0.3 M ReLU outputs) no flip occurs and the
+    comparison is strict; at 256 x 256 (7 M ReLU outputs, a handful of flips: tools/dbg_bwd.py) the criterion is the relative L2
+    error plus the fraction of elements that are off by more than 5 % of the largest gradient."""
+    cfg, sd = big2
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen.cuda().set_precision(fwd_prec)
+    fri = R.first_resblock_index(cfg)
+    batch = O.make_synthetic_batch(1, res, res, seed=6)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        z1, z2 = O.run_layers(x, sd, cfg, 0, fri)
+    z1r, z2r = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    pred_ref = O.run_layers((z1r, z2r), sd, cfg, fri, None)
+    gw = torch.randn(pred_ref.shape, generator=torch.Generator().manual_seed(7)) / pred_ref.numel()
+    (pred_ref * gw).sum().backward()
+    gref = torch.cat([z1r.grad, z2r.grad], 1)
+    rear = RearPass(gen, fri, bwd_precision=bwd_prec)
+    pred = rear.forward(torch.cat([z1, z2], 1).contiguous().to(DEV))
+    assert float((pred.cpu() - pred_ref.detach()).abs().max()) < 2e-4
+    g = rear.backward(gw.contiguous().to(DEV)).cpu()
+    d = (g - gref).abs()
+    gmax = float(gref.abs().max())
+    if res == 64:
+        assert float(d.max()) / gmax < tol, float(d.max()) / gmax
+    else:
+        l2 = float(d.norm() / gref.norm())
+        frac = float((d > 0.05 * gmax).float().mean())
+        assert l2 < 2e-2 and frac < 1e-3, (l2, frac, float(d.max()) / gmax)
+
+
+def test_refine_predict_end_to_end():
+    """refine_predict on a 2-scale pyramid (small generator, fp32 forward, bf16x3 reverse pass) against the oracle's
+    torch-autograd + Adam loop: same losses per iteration, same inpainting."""
+    cfg = O.small_config(ngf=16, n_blocks=2)
+    sd = O.make_synthetic_state_dict(cfg, seed=21, calib_hw=32)
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
+    model.load_state_dict({'generator.' + k: v for k, v in sd.items()}, strict=True)
+    model.freeze().cuda()
+    g = torch.Generator().manual_seed(5)
+    Hh, Ww = 250, 300
+    image = torch.rand(1, 3, 256, 304, generator=g)
+    mask = torch.zeros(1, 1, 256, 304)
+    mask[:, :, 40:200, 50:250] = 1.0
+    batch = dict(image=image.cuda(), mask=mask.cuda(), unpad_to_size=[torch.tensor([Hh]), torch.tensor([Ww])])
+    trace = []
+    out = RF.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=5, lr=0.002, min_side=125, max_scales=2, px_budget=10 ** 7,
+                            trace=trace)
+    ref = R.refine_predict(image, mask, (Hh, Ww), sd, cfg, modulo=8, n_iters=5, lr=0.002, min_side=125, max_scales=2, px_budget=10 ** 7)
+    assert out.shape == ref.shape == (1, 3, Hh, Ww) and len(trace) == 2 and len(trace[1]['loss']) == 5
+    assert float((out - ref).abs().max()) < 1e-2 and float((out - ref).abs().mean()) < 3e-4
+    assert trace[1]['loss'][-1] < trace[1]['loss'][0]           # the refinement does reduce its loss
