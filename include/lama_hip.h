@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 101
+#define LAMA_HIP_VERSION 102
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -47,10 +47,15 @@ extern "C" {
 #define LAMA_PREC_BF16X3 1 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_bf16: fp32 range  */
 #define LAMA_PREC_F16X3 2  /* 3-term fp16 split on v_mfma_f32_32x32x16_f16: 22 mantissa bits, |x| <= 65504     */
 
+/* element type of an activation tensor in HBM */
+#define LAMA_DT_F32 0
+#define LAMA_DT_F16 1 /* IEEE half: BASELINE configs[2] "fp16"; every tensor of a call is fp16 except where an entry says otherwise */
+
 typedef struct lama_tensor {
     void* ptr;            /* device pointer to element (0,0,0,0) of the view; NULL = absent          */
-    int64_t batch_stride; /* elements between consecutive images                                     */
+    int64_t batch_stride; /* ELEMENTS between consecutive images                                     */
     int32_t C, H, W;
+    int32_t dtype;        /* LAMA_DT_F32 (0) or LAMA_DT_F16                                          */
 } lama_tensor;
 
 /* One fused convolution launch:

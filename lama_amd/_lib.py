@@ -14,9 +14,10 @@ import torch
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
-PREC_F32, PREC_BF16X3, PREC_F16X3 = 0, 1, 2
-ABI_VERSION = 101      # LAMA_HIP_VERSION of include/lama_hip.h
-PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3}
+PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
+DT_F32, DT_F16 = 0, 1
+ABI_VERSION = 102      # LAMA_HIP_VERSION of include/lama_hip.h
+PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
 
@@ -33,7 +34,8 @@ F16_MAX = 65504.0
 
 class Tensor4(C.Structure):
     """struct lama_tensor"""
-    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32)]
+    _fields_ = [('ptr', C.c_void_p), ('batch_stride', C.c_int64), ('C', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('dtype', C.c_int32)]
 
 
 class Conv2dArgs(C.Structure):
@@ -47,16 +49,16 @@ class Conv2dArgs(C.Structure):
 
 
 def view(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Tensor4:
-    """lama_tensor view of channels [c0, c0+c) of a contiguous fp32 NCHW tensor (None -> absent)."""
+    """lama_tensor view of channels [c0, c0+c) of a contiguous fp32 / fp16 NCHW tensor (None -> absent)."""
     if t is None:
-        return Tensor4(None, 0, 0, 0, 0)
-    if t.dtype != torch.float32 or t.dim() != 4 or not t.is_contiguous():
-        raise LamaError(f'expected a contiguous fp32 NCHW tensor, got {t.dtype} {tuple(t.shape)}')
+        return Tensor4(None, 0, 0, 0, 0, 0)
+    if t.dtype not in (torch.float32, torch.float16) or t.dim() != 4 or not t.is_contiguous():
+        raise LamaError(f'expected a contiguous fp32 / fp16 NCHW tensor, got {t.dtype} {tuple(t.shape)}')
     B, Ct, H, W = t.shape
     c = Ct - c0 if c is None else c
     if c0 < 0 or c <= 0 or c0 + c > Ct:
         raise LamaError('channel slice out of range')
-    return Tensor4(t.data_ptr() + 4 * c0 * H * W, Ct * H * W, c, H, W)
+    return Tensor4(t.data_ptr() + t.element_size() * c0 * H * W, Ct * H * W, c, H, W, DT_F16 if t.dtype == torch.float16 else DT_F32)
 
 
 class LamaLib:

@@ -36,6 +36,10 @@ static inline int lama_round_up(int a, int b) { return lama_ceil_div(a, b) * b; 
 static inline bool lama_is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline int lama_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
+// Activation element types in HBM (lama_tensor.dtype): LAMA_DT_F32 or LAMA_DT_F16.  Kernels are templated on a bool (half I/O).
+template <bool H> struct LamaAct { typedef float T; static constexpr int ES = 4; };
+template <> struct LamaAct<true> { typedef _Float16 T; static constexpr int ES = 2; };
+
 // XCD-aware remap of the linear workgroup id: hardware places block i on XCD i % 8; give every XCD a
 // contiguous range of logical ids so neighbouring tiles (shared input patches / weights) hit one L2.
 // Bijective for any grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").

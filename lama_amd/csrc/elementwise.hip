@@ -1,6 +1,7 @@
 // Elementwise pre/post kernels of the inference path, the composite FourierUnit entry point and the
 // misc C-ABI functions.
 #include "common.h"
+#include <initializer_list>
 
 struct EwParams {
     const float* img;
@@ -131,6 +132,13 @@ int ew_grid(long long total) {
     return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
 }
 bool same_hw(const lama_tensor* a, const lama_tensor* b) { return a->H == b->H && a->W == b->W; }
+// the glue kernels around the generator (image / mask side) are fp32 only; the fp16 activation path (LAMA_DT_F16) starts at the
+// stem's output and ends at the head's input
+bool all_f32(std::initializer_list<const lama_tensor*> ts) {
+    for (const lama_tensor* t : ts)
+        if (t && t->ptr && t->dtype != LAMA_DT_F32) return false;
+    return true;
+}
 }  // namespace
 
 extern "C" int lama_version(void) { return LAMA_HIP_VERSION; }
@@ -149,6 +157,7 @@ extern "C" int lama_mask_compose_fwd(void* stream, const lama_tensor* image, con
                                      const lama_tensor* out, int32_t batch) {
     if (!image || !mask || !out || !image->ptr || !mask->ptr || !out->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
     if (image->C != 3 || mask->C != 1 || out->C != 4 || !same_hw(image, mask) || !same_hw(image, out)) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({image, mask, out})) return LAMA_ERR_UNSUPPORTED;
     EwParams p;
     memset(&p, 0, sizeof(p));
     p.img = (const float*)image->ptr; p.img_bs = image->batch_stride;
@@ -166,6 +175,7 @@ extern "C" int lama_blend_fwd(void* stream, const lama_tensor* image, const lama
     if (!image || !mask || !pred || !out || !image->ptr || !mask->ptr || !pred->ptr || !out->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
     if (image->C != 3 || mask->C != 1 || pred->C != 3 || out->C != 3) return LAMA_ERR_BAD_ARG;
     if (!same_hw(image, mask) || !same_hw(image, pred) || !same_hw(image, out)) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({image, mask, pred, out})) return LAMA_ERR_UNSUPPORTED;
     EwParams p;
     memset(&p, 0, sizeof(p));
     p.img = (const float*)image->ptr; p.img_bs = image->batch_stride;
@@ -183,6 +193,7 @@ extern "C" int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, ui
                                         int32_t crop_h, int32_t crop_w) {
     if (!src || !src->ptr || !dst || batch <= 0 || src->C != 3) return LAMA_ERR_BAD_ARG;
     if (crop_h <= 0 || crop_w <= 0 || crop_h > src->H || crop_w > src->W) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({src})) return LAMA_ERR_UNSUPPORTED;
     QuantParams p;
     p.src = (const float*)src->ptr; p.src_bs = src->batch_stride;
     p.dst = dst;
@@ -197,6 +208,7 @@ extern "C" int lama_affine_act_fwd(void* stream, const lama_tensor* x, const flo
                                    const lama_tensor* y, int32_t batch) {
     if (!x || !y || !x->ptr || !y->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
     if (x->C != y->C || !same_hw(x, y) || ((scale == nullptr) != (shift == nullptr))) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({x, y})) return LAMA_ERR_UNSUPPORTED;
     AffineParams p;
     p.x = (const float*)x->ptr; p.x_bs = x->batch_stride;
     p.scale = scale; p.shift = shift;
@@ -211,6 +223,7 @@ extern "C" int lama_affine_act_fwd(void* stream, const lama_tensor* x, const flo
 extern "C" int lama_reflect_pad_fwd(void* stream, const lama_tensor* x, int32_t pad, const lama_tensor* y, int32_t batch) {
     if (!x || !y || !x->ptr || !y->ptr || batch <= 0 || pad < 0) return LAMA_ERR_BAD_ARG;
     if (x->C != y->C || y->H != x->H + 2 * pad || y->W != x->W + 2 * pad || pad >= x->H || pad >= x->W) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({x, y})) return LAMA_ERR_UNSUPPORTED;
     PadParams p;
     p.x = (const float*)x->ptr; p.x_bs = x->batch_stride;
     p.y = (float*)y->ptr; p.y_bs = y->batch_stride;
@@ -237,8 +250,9 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
     if (!workspace || workspace_bytes < lama_fourier_unit_workspace_bytes(batch, C, h, w)) return LAMA_ERR_WORKSPACE;
     size_t spec_bytes = ((size_t)batch * 2 * C * h * wf * sizeof(float) + 255) & ~(size_t)255;
     char* ws = (char*)workspace;
-    lama_tensor s1 = {ws, (int64_t)2 * C * h * wf, 2 * C, h, wf};
-    lama_tensor s2 = {ws + spec_bytes, (int64_t)2 * C * h * wf, 2 * C, h, wf};
+    if (x->dtype != y->dtype) return LAMA_ERR_UNSUPPORTED;
+    lama_tensor s1 = {ws, (int64_t)2 * C * h * wf, 2 * C, h, wf, x->dtype};
+    lama_tensor s2 = {ws + spec_bytes, (int64_t)2 * C * h * wf, 2 * C, h, wf, x->dtype};
     void* fws = ws + 2 * spec_bytes;
     size_t fws_bytes = workspace_bytes - 2 * spec_bytes;
     int rc = lama_rfft2_fwd(stream, x, &s1, batch, fws, fws_bytes);

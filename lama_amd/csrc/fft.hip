@@ -126,12 +126,42 @@ __device__ __forceinline__ float2* fft_lds(float2* bufA, float2* bufB, const flo
     return src;
 }
 
+// Activation elements in HBM are fp32 or fp16 (lama_tensor.dtype; kernel template parameter HF): a typed pointer whose element
+// access converts to / from float, plus 4-element vector accesses (16 B of fp32 or 8 B of fp16, naturally aligned).
+template <bool HF>
+struct ActP {
+    using T = typename LamaAct<HF>::T;
+    T* p;
+    __device__ __forceinline__ ActP operator+(long long o) const { return ActP{p + o}; }
+    struct Ref {
+        T* q;
+        __device__ __forceinline__ operator float() const { return (float)*q; }
+        __device__ __forceinline__ void operator=(float v) const { *q = (T)v; }
+    };
+    __device__ __forceinline__ Ref operator[](long long i) const { return Ref{p + i}; }
+    __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+};
+__device__ __forceinline__ float4 fft_ld4(ActP<false> a) { return *reinterpret_cast<const float4*>(a.p); }
+__device__ __forceinline__ void fft_st4(ActP<false> a, float4 v) { *reinterpret_cast<float4*>(a.p) = v; }
+typedef _Float16 fft_h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 fft_ld4(ActP<true> a) {
+    const fft_h4 h = *reinterpret_cast<const fft_h4*>(a.p);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void fft_st4(ActP<true> a, float4 v) {
+    *reinterpret_cast<fft_h4*>(a.p) = fft_h4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+}
+#define FFT_IO(p)                                                                                                    \
+    const ActP<HF> px{(typename LamaAct<HF>::T*)const_cast<void*>((p).x)}, ps{(typename LamaAct<HF>::T*)(p).spec},   \
+        py{(typename LamaAct<HF>::T*)(p).y};                                                                         \
+    (void)px; (void)ps; (void)py
+
 struct FftParams {
-    const float* x;      // forward: input planes; inverse: residual (may be null)
-    long long x_bstride;
-    float* spec;         // forward: output; inverse: input
+    const void* x;       // forward: input planes; inverse: residual (may be null).  fp32 or fp16 elements (template parameter HF of
+    long long x_bstride; // the kernels = lama_tensor.dtype of all three tensors); strides are in ELEMENTS
+    void* spec;          // forward: output; inverse: input
     long long spec_bstride;
-    float* y;            // inverse output
+    void* y;             // inverse output
     long long y_bstride;
     int C, h, w, wf;
     int nplanes;         // B*C
@@ -167,8 +197,9 @@ __device__ __forceinline__ void rowpair_item(int item, int wq, int& f, int& q) {
 // from HBM (into registers) before it transforms plane s, so only the first plane's load latency is exposed, the twiddles are
 // set up once, and a launch of B*C planes is B*C / SEQ workgroups that are all resident at once (no tail round).
 #define FFT_STAMP(i) do { if constexpr (TR) { if (threadIdx.x == 0) p.trace[(long long)blockIdx.x * 16 + (i)] = LAMA_CLOCK(); } } while (0)
-template <int HT, int WT, int PPW, int SEQ = 1, bool TR = false>
+template <int HT, int WT, int PPW, int SEQ = 1, bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
+    FFT_IO(p);
     FFT_STAMP(0);
     static_assert(SEQ == 1 || (HT > 0 && WT > 0 && PPW == 1), "sequential planes: sized one-plane instantiations only");
     const int h = HT ? HT : p.h, w = WT ? WT : p.w, wf = w / 2 + 1, hh = h >> 1, wh = w >> 1;
@@ -189,16 +220,16 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
     float4 pra[NPF], prb[NPF];
     auto prefetch = [&](int plane) {
         const int b = plane / p.C, c = plane - b * p.C;
-        const float* base = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+        const auto base = px + (long long)b * p.x_bstride + (long long)c * h * w;
 #pragma unroll
         for (int it = 0; it < NPF; ++it) {
             const int item = tid + it * LAMA_NTHREADS;
             if (item < hh * (w >> 2)) {
                 int f, q;
                 rowpair_item(item, w >> 2, f, q);
-                const float* src = base + (2 * f) * w + q * 4;
-                pra[it] = *reinterpret_cast<const float4*>(src);
-                prb[it] = *reinterpret_cast<const float4*>(src + w);
+                const auto src = base + (2 * f) * w + q * 4;
+                pra[it] = fft_ld4(src);
+                prb[it] = fft_ld4(src + w);
             }
         }
     };
@@ -230,9 +261,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
             rowpair_item(item - pl * per_plane, wq, f, q);
             int plane = plane0 + pl;
             int b = plane / p.C, c = plane - b * p.C;
-            const float* src = p.x + (long long)b * p.x_bstride + (long long)c * h * w + (2 * f) * w + q * 4;
-            float4 ra = *reinterpret_cast<const float4*>(src);
-            float4 rb = *reinterpret_cast<const float4*>(src + w);
+            const auto src = px + (long long)b * p.x_bstride + (long long)c * h * w + (2 * f) * w + q * 4;
+            float4 ra = fft_ld4(src);
+            float4 rb = fft_ld4(src + w);
             float2* d = P + (pl * hh + f) * RSW + q * 4;
             d[0] = make_float2(ra.x, rb.x);
             d[1] = make_float2(ra.y, rb.y);
@@ -274,7 +305,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
         // from the packed column 0 on the fly (two extra LDS reads for 2 of the wf columns), which saves two barriers
         const int per_plane = h * wf;
         const int b = plane0 / p.C, c = plane0 - b * p.C;
-        float* dre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        const auto dre = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
         for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
             float re[4], im[4];
 #pragma unroll
@@ -289,8 +320,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
                 re[e] = v.x * p.scale;
                 im[e] = v.y * p.scale;
             }
-            *reinterpret_cast<float4*>(dre + i4 * 4) = make_float4(re[0], re[1], re[2], re[3]);
-            *reinterpret_cast<float4*>(dre + per_plane + i4 * 4) = make_float4(im[0], im[1], im[2], im[3]);
+            fft_st4(dre + i4 * 4, make_float4(re[0], re[1], re[2], re[3]));
+            fft_st4(dre + per_plane + i4 * 4, make_float4(im[0], im[1], im[2], im[3]));
         }
         if (sq + 1 < SEQ) __syncthreads();   // the next plane's row pairs overwrite the buffers
     } else {
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
             int plane = plane0 + pl;
             int b = plane / p.C, c = plane - b * p.C;
             float2 v = E2[pl * per_plane + i];
-            float* dst = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
+            const auto dst = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
             dst[0] = v.x * p.scale;
             dst[per_plane] = v.y * p.scale;
         }
@@ -332,8 +363,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_lds_kernel(FftParams p) {
 
 // SEQ > 1: as in rfft2_lds_kernel -- SEQ consecutive planes per workgroup, the spectrum of plane s + 1 (float4 loads of the Re / Im
 // planes) is requested before plane s is transformed, and the residual of plane s right behind its own spectrum (not at store time).
-template <int HT, int WT, int PPW, int SEQ = 1, bool TR = false>
+template <int HT, int WT, int PPW, int SEQ = 1, bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) {
+    FFT_IO(p);
     FFT_STAMP(0);
     static_assert(SEQ == 1 || (HT > 0 && WT > 0 && PPW == 1), "sequential planes: sized one-plane instantiations only");
     const int h = HT ? HT : p.h, w = WT ? WT : p.w, wf = w / 2 + 1, hh = h >> 1, wh = w >> 1;
@@ -355,27 +387,27 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
     float4 sre[NSP], sim[NSP], rxa[NRP], rxb[NRP];
     auto prefetch_spec = [&](int plane) {
         const int b = plane / p.C, c = plane - b * p.C;
-        const float* base = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        const auto base = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
 #pragma unroll
         for (int it = 0; it < NSP; ++it) {
             const int i4 = tid + it * LAMA_NTHREADS;
             if (i4 < per_plane / 4) {
-                sre[it] = *reinterpret_cast<const float4*>(base + i4 * 4);
-                sim[it] = *reinterpret_cast<const float4*>(base + per_plane + i4 * 4);
+                sre[it] = fft_ld4(base + i4 * 4);
+                sim[it] = fft_ld4(base + per_plane + i4 * 4);
             }
         }
     };
     auto prefetch_resid = [&](int plane) {
         const int b = plane / p.C, c = plane - b * p.C;
-        const float* base = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+        const auto base = px + (long long)b * p.x_bstride + (long long)c * h * w;
 #pragma unroll
         for (int it = 0; it < NRP; ++it) {
             const int item = tid + it * LAMA_NTHREADS;
             if (item < hh * (w >> 2)) {
                 int f, q;
                 rowpair_item(item, w >> 2, f, q);
-                rxa[it] = *reinterpret_cast<const float4*>(base + (2 * f) * w + q * 4);
-                rxb[it] = *reinterpret_cast<const float4*>(base + (2 * f + 1) * w + q * 4);
+                rxa[it] = fft_ld4(base + (2 * f) * w + q * 4);
+                rxb[it] = fft_ld4(base + (2 * f + 1) * w + q * 4);
             }
         }
     };
@@ -396,14 +428,14 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
                 d[3] = make_float2(sre[it].w, sim[it].w);
             }
         }
-        if (p.x) prefetch_resid(plane0);
+        if (px) prefetch_resid(plane0);
         if (sq + 1 < SEQ) prefetch_spec(plane0 + 1);
     } else {
     for (int item = tid; item < np * per_plane; item += LAMA_NTHREADS) {
         int pl = item / per_plane, i = item - pl * per_plane;
         int plane = plane0 + pl;
         int b = plane / p.C, c = plane - b * p.C;
-        const float* src = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
+        const auto src = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane + i;
         P[pl * per_plane + i] = make_float2(src[0], src[per_plane]);
     }
     }
@@ -457,7 +489,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
     // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
     if constexpr (SEQ > 1) {
         const int b = plane0 / p.C, c = plane0 - b * p.C;
-        float* ybase = p.y + (long long)b * p.y_bstride + (long long)c * h * w;
+        const auto ybase = py + (long long)b * p.y_bstride + (long long)c * h * w;
 #pragma unroll
         for (int it = 0; it < NRP; ++it) {
             const int item = tid + it * LAMA_NTHREADS;
@@ -468,13 +500,13 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
                 float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
                 float4 ra = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
                 float4 rb = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
-                if (p.x) {
+                if (px) {
                     ra.x += rxa[it].x; ra.y += rxa[it].y; ra.z += rxa[it].z; ra.w += rxa[it].w;
                     rb.x += rxb[it].x; rb.y += rxb[it].y; rb.z += rxb[it].z; rb.w += rxb[it].w;
                 }
-                float* d = ybase + (2 * f) * w + q * 4;
-                *reinterpret_cast<float4*>(d) = ra;
-                *reinterpret_cast<float4*>(d + w) = rb;
+                const auto d = ybase + (2 * f) * w + q * 4;
+                fft_st4(d, ra);
+                fft_st4(d + w, rb);
             }
         }
         if (sq + 1 < SEQ) __syncthreads();   // the next plane's spectrum overwrites the buffers
@@ -491,16 +523,16 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
             long long off = (long long)c * h * w + (2 * f) * w + q * 4;
             float4 ra = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
             float4 rb = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
-            if (p.x) {
-                const float* r = p.x + (long long)b * p.x_bstride + off;
-                float4 xa = *reinterpret_cast<const float4*>(r);
-                float4 xb = *reinterpret_cast<const float4*>(r + w);
+            if (px) {
+                const auto r = px + (long long)b * p.x_bstride + off;
+                float4 xa = fft_ld4(r);
+                float4 xb = fft_ld4(r + w);
                 ra.x += xa.x; ra.y += xa.y; ra.z += xa.z; ra.w += xa.w;
                 rb.x += xb.x; rb.y += xb.y; rb.z += xb.z; rb.w += xb.w;
             }
-            float* d = p.y + (long long)b * p.y_bstride + off;
-            *reinterpret_cast<float4*>(d) = ra;
-            *reinterpret_cast<float4*>(d + w) = rb;
+            const auto d = py + (long long)b * p.y_bstride + off;
+            fft_st4(d, ra);
+            fft_st4(d + w, rb);
         }
     }
     }   // planes of this workgroup
@@ -542,8 +574,9 @@ __device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, i
     __syncthreads();
 }
 
-template <bool TR = false>
+template <bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
+    FFT_IO(p);
     constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* P = tww + w;                       // h == w: one twiddle table
@@ -552,13 +585,13 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. row pairs straight from HBM (requested before the twiddles are computed): P[f][n] = (x[2f][n], x[2f+1][n])
     float4 ra[2], rb[2];
-    const float* xin = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+    const auto xin = px + (long long)b * p.x_bstride + (long long)c * h * w;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         int f, q;
         rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
-        ra[it] = *reinterpret_cast<const float4*>(xin + (2 * f) * w + q * 4);
-        rb[it] = *reinterpret_cast<const float4*>(xin + (2 * f + 1) * w + q * 4);
+        ra[it] = fft_ld4(xin + (2 * f) * w + q * 4);
+        rb[it] = fft_ld4(xin + (2 * f + 1) * w + q * 4);
     }
     fft_init_twiddles<false>(tww, w);
 #pragma unroll
@@ -609,7 +642,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
     // 5 + 6. float4 stores of the Re / Im planes; DC (col 0) and Nyquist (col 32) untangled from the packed column 0 on the fly
     {
         const int per_plane = h * wf;
-        float* dre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        const auto dre = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
         for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
             float re[4], im[4];
 #pragma unroll
@@ -624,14 +657,15 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
                 re[e] = v.x * p.scale;
                 im[e] = v.y * p.scale;
             }
-            *reinterpret_cast<float4*>(dre + i4 * 4) = make_float4(re[0], re[1], re[2], re[3]);
-            *reinterpret_cast<float4*>(dre + per_plane + i4 * 4) = make_float4(im[0], im[1], im[2], im[3]);
+            fft_st4(dre + i4 * 4, make_float4(re[0], re[1], re[2], re[3]));
+            fft_st4(dre + per_plane + i4 * 4, make_float4(im[0], im[1], im[2], im[3]));
         }
     }
 }
 
-template <bool TR = false>
+template <bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p) {
+    FFT_IO(p);
     constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
     constexpr int per_plane = h * wf;
     float2* tww = reinterpret_cast<float2*>(lama_smem);
@@ -640,25 +674,25 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
     const int plane = blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. the Re / Im planes (float4 loads, requested before the twiddles are computed) and the residual rows
-    const float* sbase = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    const auto sbase = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
     float4 sre[3], sim[3];
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         const int i4 = tid + it * LAMA_NTHREADS;
         if (i4 < per_plane / 4) {
-            sre[it] = *reinterpret_cast<const float4*>(sbase + i4 * 4);
-            sim[it] = *reinterpret_cast<const float4*>(sbase + per_plane + i4 * 4);
+            sre[it] = fft_ld4(sbase + i4 * 4);
+            sim[it] = fft_ld4(sbase + per_plane + i4 * 4);
         }
     }
     float4 rxa[2], rxb[2];
-    if (p.x) {
-        const float* rbase = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+    if (px) {
+        const auto rbase = px + (long long)b * p.x_bstride + (long long)c * h * w;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int f, q;
             rowpair_item(tid + it * LAMA_NTHREADS, w >> 2, f, q);
-            rxa[it] = *reinterpret_cast<const float4*>(rbase + (2 * f) * w + q * 4);
-            rxb[it] = *reinterpret_cast<const float4*>(rbase + (2 * f + 1) * w + q * 4);
+            rxa[it] = fft_ld4(rbase + (2 * f) * w + q * 4);
+            rxb[it] = fft_ld4(rbase + (2 * f + 1) * w + q * 4);
         }
     }
     fft_init_twiddles<true>(tww, w);
@@ -726,7 +760,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
     ip_pass<true>(P, tww, 8, 1, RSW);
     // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
     {
-        float* ybase = p.y + (long long)b * p.y_bstride + (long long)c * h * w;
+        const auto ybase = py + (long long)b * p.y_bstride + (long long)c * h * w;
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             int f, q;
@@ -735,13 +769,13 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
             const float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
             float4 oa = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
             float4 ob = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
-            if (p.x) {
+            if (px) {
                 oa.x += rxa[it].x; oa.y += rxa[it].y; oa.z += rxa[it].z; oa.w += rxa[it].w;
                 ob.x += rxb[it].x; ob.y += rxb[it].y; ob.z += rxb[it].z; ob.w += rxb[it].w;
             }
-            float* d = ybase + (2 * f) * w + q * 4;
-            *reinterpret_cast<float4*>(d) = oa;
-            *reinterpret_cast<float4*>(d + w) = ob;
+            const auto d = ybase + (2 * f) * w + q * 4;
+            fft_st4(d, oa);
+            fft_st4(d + w, ob);
         }
     }
 }
@@ -793,8 +827,9 @@ __device__ __forceinline__ void ipn_fft(float2* buf, const float2* tw, int estri
     ipn_pass<2, N, N / 2, INV>(buf, tw, 64, estride, fstride);
 }
 
-template <int N>
+template <int N, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
+    FFT_IO(p);
     constexpr int h = N, w = N, wf = N / 2 + 1, hh = N / 2, wh = N / 2, RSW = N + 1;
     constexpr int NLD = hh * (w / 4) / LAMA_NTHREADS;          // row-pair float4 items per thread
     constexpr int NUT = hh * wh / LAMA_NTHREADS;               // untangle items per thread
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
     const int tid = threadIdx.x;
     const int plane = blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
-    const float* xin = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+    const auto xin = px + (long long)b * p.x_bstride + (long long)c * h * w;
     {   // 1. row pairs: P[f][n] = (x[2f][n], x[2f+1][n]), in two halves (registers)
         float4 ra[NLD / 2], rb[NLD / 2];
 #pragma unroll
@@ -812,8 +847,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
             for (int it = 0; it < NLD / 2; ++it) {
                 int f, q;
                 rowpair_item(tid + (half * (NLD / 2) + it) * LAMA_NTHREADS, w >> 2, f, q);
-                ra[it] = *reinterpret_cast<const float4*>(xin + (2 * f) * w + q * 4);
-                rb[it] = *reinterpret_cast<const float4*>(xin + (2 * f + 1) * w + q * 4);
+                ra[it] = fft_ld4(xin + (2 * f) * w + q * 4);
+                rb[it] = fft_ld4(xin + (2 * f + 1) * w + q * 4);
             }
             if (half == 0) fft_init_twiddles<false>(tww, w);
 #pragma unroll
@@ -864,7 +899,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
     // 5 + 6. float4 stores of the Re / Im planes; DC and Nyquist untangled from the packed column 0 on the fly
     {
         constexpr int per_plane = h * wf;
-        float* dre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+        const auto dre = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
         for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
             float re[4], im[4];
 #pragma unroll
@@ -879,14 +914,15 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
                 re[e] = v.x * p.scale;
                 im[e] = v.y * p.scale;
             }
-            *reinterpret_cast<float4*>(dre + i4 * 4) = make_float4(re[0], re[1], re[2], re[3]);
-            *reinterpret_cast<float4*>(dre + per_plane + i4 * 4) = make_float4(im[0], im[1], im[2], im[3]);
+            fft_st4(dre + i4 * 4, make_float4(re[0], re[1], re[2], re[3]));
+            fft_st4(dre + per_plane + i4 * 4, make_float4(im[0], im[1], im[2], im[3]));
         }
     }
 }
 
-template <int N>
+template <int N, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) {
+    FFT_IO(p);
     constexpr int h = N, w = N, wf = N / 2 + 1, hh = N / 2, wh = N / 2, RSW = N + 1;
     constexpr int per_plane = h * wf;
     constexpr int NUT = hh * wh / LAMA_NTHREADS;
@@ -897,11 +933,11 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) 
     const int plane = blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. the Re / Im planes
-    const float* sbase = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    const auto sbase = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
     fft_init_twiddles<true>(tww, w);
     for (int i4 = tid; i4 < per_plane / 4; i4 += LAMA_NTHREADS) {
-        const float4 sre = *reinterpret_cast<const float4*>(sbase + i4 * 4);
-        const float4 sim = *reinterpret_cast<const float4*>(sbase + per_plane + i4 * 4);
+        const float4 sre = fft_ld4(sbase + i4 * 4);
+        const float4 sim = fft_ld4(sbase + per_plane + i4 * 4);
         float2* d = P + i4 * 4;
         d[0] = make_float2(sre.x, sim.x);
         d[1] = make_float2(sre.y, sim.y);
@@ -959,8 +995,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) 
     ipn_fft<N, true>(P, tww, 1, RSW);
     // 6. store rows 2f (real part) and 2f+1 (imaginary part), fused residual add
     {
-        float* ybase = p.y + (long long)b * p.y_bstride + (long long)c * h * w;
-        const float* rbase = p.x ? p.x + (long long)b * p.x_bstride + (long long)c * h * w : nullptr;
+        const auto ybase = py + (long long)b * p.y_bstride + (long long)c * h * w;
+        const auto rbase = px + (long long)b * p.x_bstride + (long long)c * h * w;
 #pragma unroll
         for (int it = 0; it < NST; ++it) {
             int f, q;
@@ -969,15 +1005,15 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) 
             const float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
             float4 oa = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
             float4 ob = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
-            if (rbase) {
-                const float4 xa = *reinterpret_cast<const float4*>(rbase + (2 * f) * w + q * 4);
-                const float4 xb = *reinterpret_cast<const float4*>(rbase + (2 * f + 1) * w + q * 4);
+            if (px) {
+                const float4 xa = fft_ld4(rbase + (2 * f) * w + q * 4);
+                const float4 xb = fft_ld4(rbase + (2 * f + 1) * w + q * 4);
                 oa.x += xa.x; oa.y += xa.y; oa.z += xa.z; oa.w += xa.w;
                 ob.x += xb.x; ob.y += xb.y; ob.z += xb.z; ob.w += xb.w;
             }
-            float* d = ybase + (2 * f) * w + q * 4;
-            *reinterpret_cast<float4*>(d) = oa;
-            *reinterpret_cast<float4*>(d + w) = ob;
+            const auto d = ybase + (2 * f) * w + q * 4;
+            fft_st4(d, oa);
+            fft_st4(d + w, ob);
         }
     }
 }
@@ -989,7 +1025,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) 
 #define DFT_COLS_PER_WG 8
 
 // forward rows: ws[plane][y][k] = sum_n x[y][n] e^{-2 pi i n k / w}
+template <bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_fwd_kernel(FftParams p, float2* ws) {
+    FFT_IO(p);
     const int w = p.w, wf = p.wf, h = p.h;
     float2* tw = reinterpret_cast<float2*>(lama_smem);
     float* rows = reinterpret_cast<float*>(tw + w);
@@ -1004,7 +1042,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_fwd_kernel(FftParams p
         if (row < nrows) {
             int plane = (int)(row / h), y = (int)(row - (long long)plane * h);
             int b = plane / p.C, c = plane - b * p.C;
-            v = p.x[(long long)b * p.x_bstride + ((long long)c * h + y) * w + n];
+            v = px[(long long)b * p.x_bstride + ((long long)c * h + y) * w + n];
         }
         rows[i] = v;
     }
@@ -1029,8 +1067,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_fwd_kernel(FftParams p
 
 // forward columns: spec[u][k] = scale * sum_y ws[y][k] e^{-2 pi i y u / h}; inverse columns (INV):
 // ws_out[y][k] = sum_u spec[u][k] e^{+2 pi i u y / h}
-template <bool INV>
+template <bool INV, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void dft_cols_kernel(FftParams p, float2* ws) {
+    FFT_IO(p);
     const int wf = p.wf, h = p.h;
     float2* tw = reinterpret_cast<float2*>(lama_smem);
     float2* cols = tw + h;  // [h][DFT_COLS_PER_WG]
@@ -1039,8 +1078,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_cols_kernel(FftParams p, fl
     const int plane = blockIdx.x / ncb, k0 = (blockIdx.x - plane * ncb) * DFT_COLS_PER_WG;
     const int b = plane / p.C, c = plane - b * p.C;
     const long long per_plane = (long long)h * wf;
-    float* sre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
-    float* sim = sre + per_plane;
+    const auto sre = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    const auto sim = sre + per_plane;
     fft_init_twiddles<INV>(tw, h);
     for (int i = tid; i < h * DFT_COLS_PER_WG; i += LAMA_NTHREADS) {
         int y = i / DFT_COLS_PER_WG, kk = i - y * DFT_COLS_PER_WG;
@@ -1073,7 +1112,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_cols_kernel(FftParams p, fl
 }
 
 // inverse rows (c2r ignoring Im of bins 0 and w/2): y[x] = scale*(Re z0 + (-1)^x Re z_{w/2} + 2 sum Re(z_k e^{2 pi i k x/w})) + resid
+template <bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_inv_kernel(FftParams p, const float2* ws) {
+    FFT_IO(p);
     const int w = p.w, wf = p.wf, h = p.h;
     float2* tw = reinterpret_cast<float2*>(lama_smem);
     float2* rows = tw + w;  // [ROWS][wf]
@@ -1107,8 +1148,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_inv_kernel(FftParams p
         int plane = (int)(row / h), y = (int)(row - (long long)plane * h);
         int b = plane / p.C, c = plane - b * p.C;
         long long off = ((long long)c * h + y) * w + xx;
-        if (p.x) acc += p.x[(long long)b * p.x_bstride + off];
-        p.y[(long long)b * p.y_bstride + off] = acc;
+        if (px) acc += px[(long long)b * p.x_bstride + off];
+        py[(long long)b * p.y_bstride + off] = acc;
     }
 }
 
@@ -1123,7 +1164,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_inv_kernel(FftParams p
 #define FFT2P_COLS 8    // columns per workgroup (pass C)
 
 // forward rows: ws[plane][y][k] = half spectrum of row y (unscaled)
+template <bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_fwd_kernel(FftParams p, float2* ws) {
+    FFT_IO(p);
     const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
     const int RSW = w + 1;
     float2* tw = reinterpret_cast<float2*>(lama_smem);
@@ -1135,7 +1178,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_fwd_kernel(FftParams
     const int np = (hh - f0) < FFT2P_PAIRS ? (hh - f0) : FFT2P_PAIRS;
     const int b = plane / p.C, c = plane - b * p.C;
     fft_init_twiddles<false>(tw, w);
-    const float* src = p.x + (long long)b * p.x_bstride + (long long)c * h * w;
+    const auto src = px + (long long)b * p.x_bstride + (long long)c * h * w;
     for (int i = tid; i < np * w; i += LAMA_NTHREADS) {
         int f = i / w, n = i - f * w;
         P[f * RSW + n] = make_float2(src[(long long)(2 * (f0 + f)) * w + n], src[(long long)(2 * (f0 + f) + 1) * w + n]);
@@ -1160,8 +1203,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_fwd_kernel(FftParams
 }
 
 // columns: forward (INV = false): spec[u][k] = scale * FFT_h(ws[.][k]); inverse: ws[y][k] = IFFT_h(spec[.][k]) (unscaled)
-template <bool INV>
+template <bool INV, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_cols_kernel(FftParams p, float2* ws) {
+    FFT_IO(p);
     const int h = p.h, wf = p.wf;
     const int CS = h + 1;                                        // LDS pitch of one column
     float2* tw = reinterpret_cast<float2*>(lama_smem);
@@ -1173,8 +1217,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_cols_kernel(FftParams p, 
     const int nc = (wf - k0) < FFT2P_COLS ? (wf - k0) : FFT2P_COLS;
     const int b = plane / p.C, c = plane - b * p.C;
     const long long per_plane = (long long)h * wf;
-    float* sre = p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
-    float* sim = sre + per_plane;
+    const auto sre = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    const auto sim = sre + per_plane;
     float2* wp = ws + (long long)plane * per_plane;
     fft_init_twiddles<INV>(tw, h);
     for (int i = tid; i < h * FFT2P_COLS; i += LAMA_NTHREADS) {
@@ -1198,7 +1242,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_cols_kernel(FftParams p, 
 }
 
 // inverse rows: c2r of ws rows (Im of bins 0 and w/2 ignored), two rows per complex FFT, fused residual add
+template <bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_inv_kernel(FftParams p, const float2* ws) {
+    FFT_IO(p);
     const int h = p.h, w = p.w, wf = p.wf, hh = h >> 1, wh = w >> 1;
     const int RSW = w + 1;
     float2* tw = reinterpret_cast<float2*>(lama_smem);
@@ -1229,12 +1275,12 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_inv_kernel(FftParams
         float2 v = E[f * RSW + n];
         long long oa = base + (long long)(2 * (f0 + f)) * w + n, ob = oa + w;
         float ra = v.x * p.scale, rb = v.y * p.scale;
-        if (p.x) {
-            const float* r = p.x + (long long)b * p.x_bstride;
+        if (px) {
+            const auto r = px + (long long)b * p.x_bstride;
             ra += r[oa];
             rb += r[ob];
         }
-        float* d = p.y + (long long)b * p.y_bstride;
+        const auto d = py + (long long)b * p.y_bstride;
         d[oa] = ra;
         d[ob] = rb;
     }
@@ -1301,43 +1347,53 @@ extern "C" size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, 
     return (size_t)batch * C * h * (w / 2 + 1) * sizeof(float2);
 }
 
+// launch kernel<targs..., HF> with HF = (dtype == LAMA_DT_F16); targs is a parenthesised template-argument list
+#define FFT_UNPAREN(...) __VA_ARGS__
+#define FFT_GO(name, targs, grid, blk, lds, ...)                                                        \
+    do {                                                                                                \
+        if (hf) hipLaunchKernelGGL((name<FFT_UNPAREN targs, true>), grid, blk, lds, st, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((name<FFT_UNPAREN targs, false>), grid, blk, lds, st, __VA_ARGS__);     \
+    } while (0)
+
 extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch,
                               void* workspace, size_t workspace_bytes) {
     if (!fft_args_ok(x, spec, batch)) return LAMA_ERR_BAD_ARG;
+    if (x->dtype != spec->dtype || (x->dtype != LAMA_DT_F32 && x->dtype != LAMA_DT_F16)) return LAMA_ERR_UNSUPPORTED;
+    const bool hf = x->dtype == LAMA_DT_F16;
+    const int es = hf ? 2 : 4;                    // vector accesses are 4 elements: 16-byte (fp32) / 8-byte (fp16) alignment
+    const uintptr_t amask = hf ? 7 : 15;
     FftParams p;
     memset(&p, 0, sizeof(p));
-    p.x = (const float*)x->ptr;
+    p.x = x->ptr;
     p.x_bstride = x->batch_stride;
-    p.spec = (float*)spec->ptr;
+    p.spec = spec->ptr;
     p.spec_bstride = spec->batch_stride;
     p.C = x->C; p.h = x->H; p.w = x->W; p.wf = x->W / 2 + 1;
     p.nplanes = batch * x->C;
     p.scale = (float)(1.0 / sqrt((double)p.h * (double)p.w));
     hipStream_t st = (hipStream_t)stream;
-    if (fft_fast_ok(p.h, p.w) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4)) & 15) == 0) {
+    const bool spec_al = (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * es)) & amask) == 0;
+    if (fft_fast_ok(p.h, p.w) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * es)) & amask) == 0) {
         p.ppw = fft_ppw(p.h, p.w);
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
         const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
         const bool even = p.nplanes % p.ppw == 0;
-        const int seq = (p.ppw == 1 && ((p.h == 64 && p.w == 64) || (p.h == 128 && p.w == 128)) &&
-                         (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0) ? fft_seq(p.nplanes) : 1;
-        const dim3 gseq(p.nplanes / seq);
-        p.trace = fft_trace_buf();
-        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
-            hipLaunchKernelGGL((rfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
-        else if (p.h == 128 && p.w == 128 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
-            hipLaunchKernelGGL((rfft2_ipn_kernel<128>), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), st, p);
+        p.trace = hf ? nullptr : fft_trace_buf();
+        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && spec_al)
+            FFT_GO(rfft2_ip64_kernel, (false), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), p);
+        else if (p.h == 128 && p.w == 128 && fft_inplace() && spec_al)
+            FFT_GO(rfft2_ipn_kernel, (128), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), p);
 #ifdef LAMA_PROFILING
-        else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
-        else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
-        else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
-        else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
-        else if (seq == 3 && p.h == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 3>), gseq, blk, lds, st, p);
+        else if (!hf && p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 2 && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 2>), dim3(p.nplanes / 2), blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 3 && p.h == 64 && p.w == 64) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1, 3>), dim3(p.nplanes / 3), blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 2 && p.h == 128 && p.w == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 2>), dim3(p.nplanes / 2), blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 3 && p.h == 128 && p.w == 128) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1, 3>), dim3(p.nplanes / 3), blk, lds, st, p);
 #endif
-        else if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
-        else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((rfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
-        else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
-        else hipLaunchKernelGGL((rfft2_lds_kernel<0, 0, 0>), grid, blk, lds, st, p);
+        else if (!hf && even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
+        else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) FFT_GO(rfft2_lds_kernel, (32, 32, 4, 1, false), grid, blk, lds, p);
+        else if (!hf && even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((rfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
+        else FFT_GO(rfft2_lds_kernel, (0, 0, 0, 1, false), grid, blk, lds, p);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
@@ -1347,9 +1403,10 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     if (fft_two_pass_ok(p.h, p.w)) {
         size_t ldsr = ((size_t)p.w + 2 * (size_t)FFT2P_PAIRS * (p.w + 1)) * sizeof(float2);
         size_t ldsc = ((size_t)p.h + 2 * (size_t)FFT2P_COLS * (p.h + 1)) * sizeof(float2);
-        hipLaunchKernelGGL(fft2p_rows_fwd_kernel, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, ws);
+        if (hf) hipLaunchKernelGGL(fft2p_rows_fwd_kernel<true>, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, ws);
+        else hipLaunchKernelGGL(fft2p_rows_fwd_kernel<false>, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, ws);
         LAMA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(fft2p_cols_kernel<false>, dim3(p.nplanes * lama_ceil_div(p.wf, FFT2P_COLS)), dim3(LAMA_NTHREADS), ldsc, st, p, ws);
+        FFT_GO(fft2p_cols_kernel, (false), dim3(p.nplanes * lama_ceil_div(p.wf, FFT2P_COLS)), dim3(LAMA_NTHREADS), ldsc, p, ws);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
@@ -1357,10 +1414,11 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     size_t lds1 = (size_t)p.w * sizeof(float2) + (size_t)DFT_ROWS_PER_WG * p.w * sizeof(float);
     size_t lds2 = (size_t)p.h * sizeof(float2) * (1 + DFT_COLS_PER_WG);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(dft_rows_fwd_kernel, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, ws);
+    if (hf) hipLaunchKernelGGL(dft_rows_fwd_kernel<true>, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, ws);
+    else hipLaunchKernelGGL(dft_rows_fwd_kernel<false>, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, ws);
     LAMA_CHECK_LAUNCH();
     int ncb = lama_ceil_div(p.wf, DFT_COLS_PER_WG);
-    hipLaunchKernelGGL(dft_cols_kernel<false>, dim3(p.nplanes * ncb), dim3(LAMA_NTHREADS), lds2, st, p, ws);
+    FFT_GO(dft_cols_kernel, (false), dim3(p.nplanes * ncb), dim3(LAMA_NTHREADS), lds2, p, ws);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }
@@ -1370,44 +1428,47 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     if (!fft_args_ok(y, spec, batch)) return LAMA_ERR_BAD_ARG;
     const bool has_r = resid && resid->ptr;
     if (has_r && (resid->C != y->C || resid->H != y->H || resid->W != y->W)) return LAMA_ERR_BAD_ARG;
+    if (y->dtype != spec->dtype || (has_r && resid->dtype != y->dtype) || (y->dtype != LAMA_DT_F32 && y->dtype != LAMA_DT_F16))
+        return LAMA_ERR_UNSUPPORTED;
+    const bool hf = y->dtype == LAMA_DT_F16;
+    const int es = hf ? 2 : 4;
+    const uintptr_t amask = hf ? 7 : 15;
     FftParams p;
     memset(&p, 0, sizeof(p));
-    p.x = has_r ? (const float*)resid->ptr : nullptr;
+    p.x = has_r ? resid->ptr : nullptr;
     p.x_bstride = has_r ? resid->batch_stride : 0;
-    p.spec = (float*)spec->ptr;
+    p.spec = spec->ptr;
     p.spec_bstride = spec->batch_stride;
-    p.y = (float*)y->ptr;
+    p.y = y->ptr;
     p.y_bstride = y->batch_stride;
     p.C = y->C; p.h = y->H; p.w = y->W; p.wf = y->W / 2 + 1;
     p.nplanes = batch * y->C;
     p.scale = (float)(1.0 / sqrt((double)p.h * (double)p.w));
     hipStream_t st = (hipStream_t)stream;
-    uintptr_t al = (uintptr_t)y->ptr | (uintptr_t)(y->batch_stride * 4);
-    if (has_r) al |= (uintptr_t)resid->ptr | (uintptr_t)(resid->batch_stride * 4);
-    if (fft_fast_ok(p.h, p.w) && (al & 15) == 0) {
+    uintptr_t al = (uintptr_t)y->ptr | (uintptr_t)(y->batch_stride * es);
+    if (has_r) al |= (uintptr_t)resid->ptr | (uintptr_t)(resid->batch_stride * es);
+    const bool spec_al = (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * es)) & amask) == 0;
+    if (fft_fast_ok(p.h, p.w) && (al & amask) == 0) {
         p.ppw = fft_ppw(p.h, p.w);
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
         const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
         const bool even = p.nplanes % p.ppw == 0;
-        const int seq = (p.ppw == 1 && ((p.h == 64 && p.w == 64) || (p.h == 128 && p.w == 128)) &&
-                         (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0) ? fft_seq(p.nplanes) : 1;
-        const dim3 gseq(p.nplanes / seq);
-        p.trace = fft_trace_buf();
-        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
-            hipLaunchKernelGGL((irfft2_ip64_kernel<false>), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p);
-        else if (p.h == 128 && p.w == 128 && fft_inplace() && (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * 4)) & 15) == 0)
-            hipLaunchKernelGGL((irfft2_ipn_kernel<128>), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), st, p);
+        p.trace = hf ? nullptr : fft_trace_buf();
+        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && spec_al)
+            FFT_GO(irfft2_ip64_kernel, (false), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), p);
+        else if (p.h == 128 && p.w == 128 && fft_inplace() && spec_al)
+            FFT_GO(irfft2_ipn_kernel, (128), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), p);
 #ifdef LAMA_PROFILING
-        else if (p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
-        else if (seq == 2 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 2>), gseq, blk, lds, st, p);
-        else if (seq == 3 && p.h == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 3>), gseq, blk, lds, st, p);
-        else if (seq == 2 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 2>), gseq, blk, lds, st, p);
-        else if (seq == 3 && p.h == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 3>), gseq, blk, lds, st, p);
+        else if (!hf && p.trace && even && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 1, true>), grid, blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 2 && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 2>), dim3(p.nplanes / 2), blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 3 && p.h == 64 && p.w == 64) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1, 3>), dim3(p.nplanes / 3), blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 2 && p.h == 128 && p.w == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 2>), dim3(p.nplanes / 2), blk, lds, st, p);
+        else if (!hf && spec_al && p.ppw == 1 && fft_seq(p.nplanes) == 3 && p.h == 128 && p.w == 128) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1, 3>), dim3(p.nplanes / 3), blk, lds, st, p);
 #endif
-        else if (even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
-        else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) hipLaunchKernelGGL((irfft2_lds_kernel<32, 32, 4>), grid, blk, lds, st, p);
-        else if (even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
-        else hipLaunchKernelGGL((irfft2_lds_kernel<0, 0, 0>), grid, blk, lds, st, p);
+        else if (!hf && even && p.h == 64 && p.w == 64 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<64, 64, 1>), grid, blk, lds, st, p);
+        else if (even && p.h == 32 && p.w == 32 && p.ppw == 4) FFT_GO(irfft2_lds_kernel, (32, 32, 4, 1, false), grid, blk, lds, p);
+        else if (!hf && even && p.h == 128 && p.w == 128 && p.ppw == 1) hipLaunchKernelGGL((irfft2_lds_kernel<128, 128, 1>), grid, blk, lds, st, p);
+        else FFT_GO(irfft2_lds_kernel, (0, 0, 0, 1, false), grid, blk, lds, p);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
@@ -1417,9 +1478,10 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     if (fft_two_pass_ok(p.h, p.w)) {
         size_t ldsr = ((size_t)p.w + 2 * (size_t)FFT2P_PAIRS * (p.w + 1)) * sizeof(float2);
         size_t ldsc = ((size_t)p.h + 2 * (size_t)FFT2P_COLS * (p.h + 1)) * sizeof(float2);
-        hipLaunchKernelGGL(fft2p_cols_kernel<true>, dim3(p.nplanes * lama_ceil_div(p.wf, FFT2P_COLS)), dim3(LAMA_NTHREADS), ldsc, st, p, ws);
+        FFT_GO(fft2p_cols_kernel, (true), dim3(p.nplanes * lama_ceil_div(p.wf, FFT2P_COLS)), dim3(LAMA_NTHREADS), ldsc, p, ws);
         LAMA_CHECK_LAUNCH();
-        hipLaunchKernelGGL(fft2p_rows_inv_kernel, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, (const float2*)ws);
+        if (hf) hipLaunchKernelGGL(fft2p_rows_inv_kernel<true>, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, (const float2*)ws);
+        else hipLaunchKernelGGL(fft2p_rows_inv_kernel<false>, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, (const float2*)ws);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
@@ -1428,9 +1490,10 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     size_t lds2 = (size_t)p.h * sizeof(float2) * (1 + DFT_COLS_PER_WG);
     if (lds1 > 160 * 1024 || lds2 > 160 * 1024) return LAMA_ERR_UNSUPPORTED;
     int ncb = lama_ceil_div(p.wf, DFT_COLS_PER_WG);
-    hipLaunchKernelGGL(dft_cols_kernel<true>, dim3(p.nplanes * ncb), dim3(LAMA_NTHREADS), lds2, st, p, ws);
+    FFT_GO(dft_cols_kernel, (true), dim3(p.nplanes * ncb), dim3(LAMA_NTHREADS), lds2, p, ws);
     LAMA_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dft_rows_inv_kernel, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, (const float2*)ws);
+    if (hf) hipLaunchKernelGGL(dft_rows_inv_kernel<true>, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, (const float2*)ws);
+    else hipLaunchKernelGGL(dft_rows_inv_kernel<false>, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, (const float2*)ws);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }

@@ -12,7 +12,7 @@ int rf_grid(long long total) {
     long long g = (total + LAMA_NTHREADS - 1) / LAMA_NTHREADS;
     return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
 }
-bool rf_ok(const lama_tensor* t) { return t && t->ptr && t->C > 0 && t->H > 0 && t->W > 0 && t->batch_stride >= (int64_t)t->C * t->H * t->W; }
+bool rf_ok(const lama_tensor* t) { return t && t->ptr && t->dtype == LAMA_DT_F32 && t->C > 0 && t->H > 0 && t->W > 0 && t->batch_stride >= (int64_t)t->C * t->H * t->W; }
 bool rf_same(const lama_tensor* a, const lama_tensor* b) { return a->C == b->C && a->H == b->H && a->W == b->W; }
 
 __device__ __forceinline__ int rf_reflect(int i, int n) {

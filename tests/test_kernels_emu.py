@@ -277,3 +277,28 @@ def test_f16_split_range_watch_emulated():
     with pytest.raises(L.LamaRangeError):                                  # weights are checked by the host at pack time
         lib.pack_conv_weight(torch.full((8, 8, 1, 1), 7.0e4), None, precision=L.PREC_F16X3)
     lib.pack_conv_weight(torch.full((8, 8, 1, 1), 7.0e4), None, precision=L.PREC_BF16X3)
+
+
+@pytest.mark.parametrize('hw', [(64, 64), (128, 128), (32, 32), (16, 32), (10, 12), (256, 32)], ids=lambda s: f'{s[0]}x{s[1]}')
+def test_rfft2_irfft2_fp16_io_emulated(hw):
+    """LAMA_DT_F16 tensors (BASELINE configs[2]): fp16 planes / spectra in memory, fp32 arithmetic inside the kernel.  Against the
+    fp32 reference on the fp16-rounded inputs, within fp16 output rounding."""
+    lib = emu_lib()
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 7 + w)
+    B, Cn = 2, 4
+    wide = torch.randn(B, Cn + 1, h, w, generator=g).half()
+    x = wide[:, 1:].float()
+    spec = torch.zeros(B, 2 * Cn, h, w // 2 + 1, dtype=torch.float16)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4)
+    lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, ws)
+    ref = _spec_ref(x)
+    assert torch.allclose(spec.float(), ref, atol=2e-3 * float(ref.abs().max()), rtol=2e-3), float((spec.float() - ref).abs().max())
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g)).half()
+    resid = torch.randn(B, Cn, h, w, generator=g).half()
+    y = torch.zeros(B, Cn, h, w, dtype=torch.float16)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y), B, ws)
+    ref2 = resid.float() + _inv_ref(spec2.float(), h, w)
+    assert torch.allclose(y.float(), ref2, atol=4e-3, rtol=2e-3), float((y.float() - ref2).abs().max())
+    with pytest.raises(L.LamaError):
+        lib.rfft2(L.view(wide, 1, Cn), L.view(spec.float()), B, ws)          # mixed element types
