@@ -46,6 +46,10 @@ extern "C" {
 #define LAMA_PREC_F32 0    /* v_mfma_f32_32x32x2_f32: exact fp32 (bitwise an fmaf chain)          */
 #define LAMA_PREC_BF16X3 1 /* 3-term bf16 split (hi*hi + hi*lo + lo*hi) on v_mfma_f32_32x32x16_bf16: fp32 range  */
 #define LAMA_PREC_F16X3 2  /* 3-term fp16 split on v_mfma_f32_32x32x16_f16: 22 mantissa bits, |x| <= 65504     */
+#define LAMA_PREC_F16 3    /* BASELINE configs[2] "fp16": fp16 activations in HBM (lama_tensor.dtype = LAMA_DT_F16), fp16 weights (the hi
+                            * part of the LAMA_PREC_F16X3 packing), ONE v_mfma_f32_32x32x16_f16 product per MAC, fp32 accumulation,
+                            * fp32 epilogue (bias, activation, residual), fp16 store.  x, x2 share one element type, resid and y share
+                            * one; fp32 -> fp16 (the stem) and fp16 -> fp32 (the head) are allowed.                                    */
 
 /* element type of an activation tensor in HBM */
 #define LAMA_DT_F32 0

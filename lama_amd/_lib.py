@@ -144,7 +144,7 @@ class LamaLib:
         nbytes = self._l.lama_conv2d_packed_weight_bytes(cout, cin, kh, kw, stride, int(transposed), precision)
         if nbytes <= 0:
             raise LamaError(f'unsupported conv geometry {tuple(w.shape)} stride={stride} transposed={transposed}')
-        if precision == PREC_F16X3 and w.numel():
+        if precision in (PREC_F16X3, PREC_F16) and w.numel():
             # the fp16 split of the WEIGHTS is checked here, once (activations: range_flag of lama_conv2d_args)
             ws = w if scale is None else w * (scale.float().view(1, -1, 1, 1) if transposed else scale.float().view(-1, 1, 1, 1))
             amax = float(ws.abs().max())

@@ -76,6 +76,8 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #define LAMA_BUF_RSRC(ptr, bytes) lama_make_buf(ptr, bytes)
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0)
+#define LAMA_BUF_LOAD_B16(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, soff, 0)     // 16-bit element, zero-extended
+#define LAMA_BUF_STORE_B16(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(val), rsrc, voff, soff, 0)
 // out-of-range buffer stores are dropped: a predicated store without a branch
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b32(val, rsrc, voff, soff, 0)
 #define LAMA_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)

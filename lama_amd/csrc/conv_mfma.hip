@@ -430,7 +430,7 @@ extern "C" int64_t lama_conv2d_packed_weight_bytes(int32_t cout, int32_t cin, in
     ConvPlan pl;
     if (cout <= 0 || cin <= 0) return LAMA_ERR_UNSUPPORTED;
     if (precision == LAMA_PREC_BF16X3) return lama_cb_packed_weight_bytes_bf16x3(cout, cin, kh, kw, stride, transposed);
-    if (precision == LAMA_PREC_F16X3) return lama_cb_packed_weight_bytes_f16x3(cout, cin, kh, kw, stride, transposed);
+    if (precision == LAMA_PREC_F16X3 || precision == LAMA_PREC_F16) return lama_cb_packed_weight_bytes_f16x3(cout, cin, kh, kw, stride, transposed);
     if (precision != LAMA_PREC_F32) return LAMA_ERR_UNSUPPORTED;
     if (!make_plan(cout, cin, kh, kw, stride, transposed ? 1 : kh / 2, transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
     return pl.total_floats * (int64_t)sizeof(float);
@@ -441,7 +441,7 @@ extern "C" int lama_conv2d_pack_weight(void* stream, const float* w, const float
                                        void* dst) {
     if (!w || !dst || cout <= 0 || cin <= 0) return LAMA_ERR_BAD_ARG;
     if (precision == LAMA_PREC_BF16X3) return lama_cb_pack_weight_bf16x3((hipStream_t)stream, w, scale, cout, cin, kh, kw, stride, transposed, dst);
-    if (precision == LAMA_PREC_F16X3) return lama_cb_pack_weight_f16x3((hipStream_t)stream, w, scale, cout, cin, kh, kw, stride, transposed, dst);
+    if (precision == LAMA_PREC_F16X3 || precision == LAMA_PREC_F16) return lama_cb_pack_weight_f16x3((hipStream_t)stream, w, scale, cout, cin, kh, kw, stride, transposed, dst);
     if (precision != LAMA_PREC_F32) return LAMA_ERR_UNSUPPORTED;
     ConvPlan pl;
     if (!make_plan(cout, cin, kh, kw, stride, transposed ? 1 : kh / 2, transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
@@ -471,7 +471,15 @@ extern "C" int lama_conv2d_pack_weight(void* stream, const float* w, const float
 
 extern "C" int lama_conv2d_fwd(void* stream, const lama_conv2d_args* a) {
     if (!a || !tensor_ok(a->x) || !tensor_ok(a->y) || !a->w_packed || a->batch <= 0) return LAMA_ERR_BAD_ARG;
-    if (a->precision != LAMA_PREC_F32 && a->precision != LAMA_PREC_BF16X3 && a->precision != LAMA_PREC_F16X3) return LAMA_ERR_UNSUPPORTED;
+    if (a->precision != LAMA_PREC_F32 && a->precision != LAMA_PREC_BF16X3 && a->precision != LAMA_PREC_F16X3 && a->precision != LAMA_PREC_F16)
+        return LAMA_ERR_UNSUPPORTED;
+    {   // element types: fp16 tensors only with LAMA_PREC_F16 (and LAMA_PREC_F16 only with them: at least x or y is fp16)
+        const bool xh = a->x.dtype == LAMA_DT_F16, yh = a->y.dtype == LAMA_DT_F16;
+        if ((a->x.dtype != LAMA_DT_F32 && !xh) || (a->y.dtype != LAMA_DT_F32 && !yh)) return LAMA_ERR_BAD_ARG;
+        if (a->x2.ptr && a->x2.dtype != a->x.dtype) return LAMA_ERR_BAD_ARG;
+        if (a->resid.ptr && a->resid.dtype != a->y.dtype) return LAMA_ERR_BAD_ARG;
+        if ((xh || yh) != (a->precision == LAMA_PREC_F16)) return LAMA_ERR_UNSUPPORTED;
+    }
     const int cout = a->y.C, cin = a->x.C;
     ConvPlan pl;
     if (!make_plan(cout, cin, a->kh, a->kw, a->stride, a->pad, a->transposed, &pl)) return LAMA_ERR_UNSUPPORTED;
@@ -489,7 +497,7 @@ extern "C" int lama_conv2d_fwd(void* stream, const lama_conv2d_args* a) {
     if (has2 && (a->transposed || !a->w2_packed || a->x2.H != Ho || a->x2.W != Wo || !tensor_ok(a->x2))) return LAMA_ERR_BAD_ARG;
     if (a->resid.ptr && (a->resid.C != cout || a->resid.H != Ho || a->resid.W != Wo)) return LAMA_ERR_BAD_ARG;
     if (a->precision == LAMA_PREC_BF16X3) return lama_cb_conv2d_fwd_bf16x3((hipStream_t)stream, a, Ho, Wo);
-    if (a->precision == LAMA_PREC_F16X3) return lama_cb_conv2d_fwd_f16x3((hipStream_t)stream, a, Ho, Wo);
+    if (a->precision == LAMA_PREC_F16X3 || a->precision == LAMA_PREC_F16) return lama_cb_conv2d_fwd_f16x3((hipStream_t)stream, a, Ho, Wo);
 
     ConvPlan pl2;
     if (has2 && !make_plan(cout, a->x2.C, 1, 1, 1, 0, 0, &pl2)) return LAMA_ERR_UNSUPPORTED;

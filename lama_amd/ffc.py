@@ -86,8 +86,8 @@ def _check_input(x: torch.Tensor):
     if not x.is_cuda:
         raise LamaError('lama_amd runs on an MI355X only: input tensor is on ' + str(x.device) +
                         ' (there is no CPU fallback; the CPU oracle lives in oracle/ for tests)')
-    if x.dtype != torch.float32:
-        raise LamaError(f'fp32 activations expected, got {x.dtype}')
+    if x.dtype not in (torch.float32, torch.float16):
+        raise LamaError(f'fp32 (or, with precision f16, fp16) activations expected, got {x.dtype}')
 
 
 class _Exec:
@@ -123,7 +123,7 @@ class _Exec:
     @contextlib.contextmanager
     def range_scope(self, t: torch.Tensor, precision: int):
         outer = self._depth == 0
-        if outer and precision == L.PREC_F16X3:
+        if outer and precision in (L.PREC_F16X3, L.PREC_F16):
             key = str(t.device)
             if key not in self._flags:
                 self._flags[key] = torch.zeros(1, dtype=torch.int32, device=t.device)
@@ -145,15 +145,20 @@ class _Exec:
                                      're-run with precision bf16x3 (fp32 exponent range) or f32')
 
     def conv2d(self, *a, **kw):
-        flag = self._cur_flag if kw.get('precision') == L.PREC_F16X3 else None
+        flag = self._cur_flag if kw.get('precision') in (L.PREC_F16X3, L.PREC_F16) else None
         self.lib.conv2d(*a, range_flag=flag, **kw)
 
     def fourier_unit(self, *a, precision: int = L.PREC_F32, stream: int = 0):
-        flag = self._cur_flag if precision == L.PREC_F16X3 else None
+        flag = self._cur_flag if precision in (L.PREC_F16X3, L.PREC_F16) else None
         self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag)
 
 
 _DEFAULT_EXEC = _Exec()
+
+
+def _act_dtype(precision: int) -> torch.dtype:
+    """Element type of the activation tensors in HBM: fp16 for PREC_F16 (BASELINE configs[2]), fp32 otherwise."""
+    return torch.float16 if precision == L.PREC_F16 else torch.float32
 
 
 class _HipModule(nn.Module):
@@ -234,7 +239,7 @@ class FourierUnit(_HipModule):
     def workspace(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
         n = self._exec.lib.fourier_unit_workspace_bytes(b, c, h, w)
-        return torch.empty(n // 4 + 1, dtype=torch.float32, device=x.device)
+        return torch.empty(n // 4 + 1, dtype=torch.float32, device=x.device)      # sized for fp32 spectra; fp16 ones use half of it
 
     def forward(self, x: torch.Tensor, add_input: bool = False) -> torch.Tensor:
         self._exec.check(x)
@@ -286,11 +291,11 @@ class SpectralTransform(_HipModule):
             if self._packed is None or self._packed.get('fused_scale') not in (None, 'none'):
                 self._packed = None
                 self._pack(None)
-            x1 = torch.empty(b, half, h, w, device=x.device, dtype=torch.float32)
+            x1 = torch.empty(b, half, h, w, device=x.device, dtype=x.dtype)
             t = torch.empty_like(x1)
             st = self._exec.stream(x)
             self.run_front(L.view(x), x1, t, self.fu.workspace(x1), b, st)
-            y = torch.empty(b, self.conv2.out_channels, h, w, device=x.device, dtype=torch.float32)
+            y = torch.empty(b, self.conv2.out_channels, h, w, device=x.device, dtype=x.dtype)
             self._exec.conv2d(L.view(t), self._packed['w2'], L.view(y), b, 1, precision=self.precision, stream=st)
         return y
 
@@ -419,7 +424,7 @@ class FFC(_HipModule):
             return None
         B, _, H, W = src_shape
         half = self.convg2g.conv2.in_channels
-        x1 = torch.empty(B, half, H, W, device=device, dtype=torch.float32)
+        x1 = torch.empty(B, half, H, W, device=device, dtype=_act_dtype(self.precision))
         return dict(x1=x1, t=torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
 
     def forward(self, x):
@@ -433,7 +438,7 @@ class FFC(_HipModule):
         with self._exec.range_scope(src, self.precision):
             if self._packed is None or (self.in_cg and (self.convg2g._packed or {}).get('fused_scale') != 'none'):
                 self._packed = self.pack()
-            dst = torch.empty(self.out_shape(src.shape), device=src.device, dtype=torch.float32)
+            dst = torch.empty(self.out_shape(src.shape), device=src.device, dtype=_act_dtype(self.precision))
             self.launch(self._packed, L.ACT_NONE, src, dst, self.make_scratch(src.shape, src.device))
         return (dst[:, :self.out_cl] if self.out_cl else 0), (dst[:, self.out_cl:] if self.out_cg else 0)
 
@@ -489,7 +494,7 @@ class FFC_BN_ACT(_HipModule):
         src, cl, cg = _pair_buffer(x_l, x_g)
         if cl != self.ffc.in_cl or cg != self.ffc.in_cg:
             raise LamaError(f'FFC_BN_ACT expected ({self.ffc.in_cl},{self.ffc.in_cg}) local/global channels, got ({cl},{cg})')
-        dst = torch.empty(self.out_shape(src.shape, extra_pad), device=src.device, dtype=torch.float32)
+        dst = torch.empty(self.out_shape(src.shape, extra_pad), device=src.device, dtype=_act_dtype(self.precision))
         with self._exec.range_scope(src, self.precision):
             self.run(src, dst, self.make_scratch(src.shape, src.device), None, extra_pad)
         ocl, ocg = self.ffc.out_cl, self.ffc.out_cg
@@ -612,7 +617,7 @@ class ConvTranspose2dUp(nn.ConvTranspose2d, _HipModule):
         self._exec.check(x)
         x = x.contiguous()
         B, _, H, W = x.shape
-        y = torch.empty(B, self.out_channels, 2 * H, 2 * W, device=x.device, dtype=torch.float32)
+        y = torch.empty(B, self.out_channels, 2 * H, 2 * W, device=x.device, dtype=_act_dtype(self.precision))
         with self._exec.range_scope(x, self.precision):
             self.run(x, y, bn, act)
         return y
@@ -768,7 +773,8 @@ class FFCResNetGenerator(_HipModule):
         pad_pending = 0
 
         def new(name, shp):
-            bufs[name] = torch.empty(shp, device=device, dtype=torch.float32)
+            # PREC_F16: every activation between the stem's output and the head's input is fp16; the image that leaves the head is fp32
+            bufs[name] = torch.empty(shp, device=device, dtype=torch.float32 if name == 'out' else _act_dtype(self.precision))
             return name
 
         scratch = None
@@ -851,7 +857,7 @@ class FFCResNetGenerator(_HipModule):
             with self._exec.range_scope(x, self.precision):
                 return self._forward(x)
         except LamaRangeError as e:
-            if not self.auto_fallback or self.precision != L.PREC_F16X3:
+            if not self.auto_fallback or self.precision not in (L.PREC_F16X3, L.PREC_F16):
                 raise
             warnings.warn(f'lama_amd: {e}; switching this generator to the 3-term bf16 split (PREC_BF16X3)')
             self.set_precision(L.PREC_BF16X3)

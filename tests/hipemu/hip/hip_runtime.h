@@ -275,6 +275,18 @@ static inline void hipemu_buf_store_b32(lama_buf_t r, unsigned v, unsigned voff,
     unsigned long long o = (unsigned long long)voff + soff;
     if (o + 4 <= r.n) memcpy(const_cast<char*>(r.p) + o, &v, 4);
 }
+static inline unsigned short hipemu_buf_load_b16(lama_buf_t r, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    unsigned short v = 0;
+    if (o + 2 <= r.n) memcpy(&v, r.p + o, 2);
+    return v;
+}
+static inline void hipemu_buf_store_b16(lama_buf_t r, unsigned short v, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    if (o + 2 <= r.n) memcpy(const_cast<char*>(r.p) + o, &v, 2);
+}
+#define LAMA_BUF_LOAD_B16(rsrc, voff, soff) hipemu_buf_load_b16(rsrc, voff, soff)
+#define LAMA_BUF_STORE_B16(rsrc, val, voff, soff) hipemu_buf_store_b16(rsrc, (unsigned short)(val), voff, soff)
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) hipemu_buf_store_b32(rsrc, val, voff, soff)
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)

@@ -171,3 +171,27 @@ def test_f16_split_overflow_falls_back_to_bf16x3():
     assert torch.isfinite(yb).all() and float(err.mean()) < 1e-3 and float((err < 1e-3).float().mean()) > 0.97, (float(err.mean()), float((err < 1e-3).float().mean()))
     y1 = gen(x)                                               # and the in-range input still matches on the bf16 split
     assert float((y1 - y0).abs().max()) < 1e-3, float((y1 - y0).abs().max())
+
+
+def test_generator_fp16_activation_path(small):
+    """BASELINE configs[2] "fp16" = PREC_F16: fp16 activations in memory between the stem and the head, fp16 weights, one MFMA
+    product per MAC, fp32 accumulation.  Tolerance 5e-3 max-abs on the sigmoid output (the fp32-class paths are
+    held to 2e-4), and the layer-by-layer Sequential agrees with the fused plan."""
+    from lama_amd import _lib as L
+    cfg, sd, gen = small
+    batch = O.make_synthetic_batch(2, 64, 64, seed=9)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        ref = O.generator_forward(x, sd, cfg)
+    gen.set_precision(L.PREC_F16)
+    try:
+        y = gen(x)
+        assert y.dtype == torch.float32 and float((y - ref).abs().max()) < 5e-3, float((y - ref).abs().max())
+        plan = next(iter(gen._plans.values()))
+        assert all(b.dtype == torch.float16 for n, b in plan['bufs'].items() if n != 'out') and plan['bufs']['out'].dtype == torch.float32
+        z = gen.model[0:5](x)
+        assert z[0].dtype == torch.float16
+        y2 = gen.model[5:](z)
+        assert float((y2 - y).abs().max()) < 1e-6
+    finally:
+        gen.set_precision(L.PREC_F16X3)

@@ -302,3 +302,94 @@ def test_rfft2_irfft2_fp16_io_emulated(hw):
     assert torch.allclose(y.float(), ref2, atol=4e-3, rtol=2e-3), float((y.float() - ref2).abs().max())
     with pytest.raises(L.LamaError):
         lib.rfft2(L.view(wide, 1, Cn), L.view(spec.float()), B, ws)          # mixed element types
+
+
+def _conv_f16_ref(x, w, stride, pad, reflect, transposed, bias, act, resid, x2=None, w2=None, scale=None):
+    """LAMA_PREC_F16: fp16 activations and fp16 (BatchNorm-folded) weights, exact products, fp32 accumulation / epilogue."""
+    if scale is not None:
+        w = w * (scale[None, :, None, None] if transposed else scale[:, None, None, None])
+        if w2 is not None:
+            w2 = w2 * scale[:, None, None, None]
+    return _conv_ref(x.float(), w.half().float(), stride, pad, reflect, transposed, bias, act, None if resid is None else resid.float(),
+                     x2=None if x2 is None else x2.float(), w2=None if w2 is None else w2.half().float())
+
+
+F16_CASES = [
+    # persistent pointwise GEMM (conv_ws_dev.inc)
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True),
+    dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False),
+    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True),
+    # weights-in-registers kernels (conv_wreg_dev.inc)
+    dict(cin=64, cout=130, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True),
+    dict(cin=32, cout=96, k=3, stride=1, pad=1, H=5, W=6, act=0, bias=False, resid=False, scale=False),
+    dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),
+    dict(cin=128, cout=384, k=1, stride=1, pad=0, H=5, W=33, act=1, bias=True, resid=True, scale=True),
+    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=9, W=16, act=1, bias=True, resid=True, scale=True),
+    # LDS-staged kernel (conv_split3.inc): 3x3, stride 2, transposed, 1x1 fallbacks, channel tails
+    dict(cin=8, cout=16, k=3, stride=1, pad=1, H=12, W=20, act=1, bias=True, resid=True, scale=True),
+    dict(cin=12, cout=40, k=3, stride=1, pad=1, H=9, W=7, act=0, bias=False, resid=False, scale=False),
+    dict(cin=8, cout=16, k=3, stride=2, pad=1, H=16, W=24, act=1, bias=True, resid=False, scale=True),
+    dict(cin=6, cout=16, k=3, stride=2, pad=1, H=10, W=14, act=1, bias=True, resid=False, scale=True),
+    dict(cin=24, cout=12, k=1, stride=1, pad=0, H=6, W=11, act=1, bias=True, resid=False, scale=True),
+    dict(cin=16, cout=8, k=3, stride=2, pad=1, H=8, W=12, act=1, bias=True, resid=False, scale=True, transposed=True),
+    dict(cin=20, cout=36, k=3, stride=2, pad=1, H=5, W=7, act=0, bias=True, resid=False, scale=False, transposed=True),
+    dict(cin=24, cout=70, k=3, stride=2, pad=1, H=9, W=34, act=1, bias=True, resid=False, scale=True, transposed=True),
+    dict(cin=140, cout=130, k=3, stride=1, pad=1, H=8, W=8, act=1, bias=True, resid=True, scale=True),
+]
+# the two ends of the fp16 path: the stem reads the fp32 network input, the head writes the fp32 image
+F16_STEM_HEAD = [
+    (dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True), torch.float32, torch.float16),
+    (dict(cin=64, cout=3, k=7, stride=1, pad=3, H=10, W=40, act=2, bias=True, resid=False, scale=False), torch.float16, torch.float32),
+]
+
+
+def _run_f16_case(lib, case, x_dtype=torch.float16, y_dtype=torch.float16):
+    g = torch.Generator().manual_seed(3)
+    B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
+    tr = case.get('transposed', False)
+    x = torch.randn(B, cin, case['H'], case['W'], generator=g).to(x_dtype)
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
+    bias = torch.randn(cout, generator=g) if case['bias'] else None
+    ref0 = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
+    resid = torch.randn(ref0.shape, generator=g).to(y_dtype) if case['resid'] else None
+    ref = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
+    wp = lib.pack_conv_weight(w, scale, stride=case['stride'], transposed=tr, precision=L.PREC_F16)
+    ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0, dtype=y_dtype)
+    lib.conv2d(L.view(x), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'], L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
+               case['act'], None if resid is None else L.view(resid), precision=L.PREC_F16)
+    y = ybuf[:, 2:2 + cout].float()
+    tol = 2e-3 * max(1.0, float(ref.abs().max())) if y_dtype == torch.float16 else 1e-4     # one fp16 rounding of the output
+    assert float((y - ref).abs().max()) < tol, float((y - ref).abs().max())
+    assert float(ybuf[:, :2].float().min()) == 7.0 and float(ybuf[:, -1].float().max()) == 7.0
+
+
+@pytest.mark.parametrize('case', F16_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d_fp16_io_emulated(case):
+    _run_f16_case(emu_lib(), case)
+
+
+@pytest.mark.parametrize('cg_', [160, 384], ids=['cg160', 'cg384'])
+def test_conv2d_fp16_fused_second_operand_wreg_emulated(cg_):
+    """The bottleneck global-branch launch (3x3 over x_l + 1x1 over t + bias + ReLU + residual) with fp16 activations."""
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(3)
+    B, cl, cg, half, H, W = 2, 32, cg_, 64, 6, 35
+    state = torch.randn(B, cl + cg, H, W, generator=g).half()
+    t = torch.randn(B, half, H, W, generator=g).half()
+    w1 = torch.randn(cg, cl, 3, 3, generator=g) * 0.2
+    w2 = torch.randn(cg, half, 1, 1, generator=g) * 0.2
+    scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
+    ref = _conv_f16_ref(state[:, :cl], w1, 1, 1, True, False, bias, 1, state[:, cl:], x2=t, w2=w2, scale=scale)
+    out = torch.zeros_like(state)
+    lib.conv2d(L.view(state, 0, cl), lib.pack_conv_weight(w1, scale, precision=L.PREC_F16), L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT,
+               False, bias, L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale, precision=L.PREC_F16),
+               precision=L.PREC_F16)
+    err = float((out[:, cl:].float() - ref).abs().max())
+    assert err < 2e-3 * max(1.0, float(ref.abs().max())), err
+    assert float(out[:, :cl].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('case,xdt,ydt', F16_STEM_HEAD, ids=['stem_f32_to_f16', 'head_f16_to_f32'])
+def test_conv2d_fp16_stem_head_emulated(case, xdt, ydt):
+    _run_f16_case(emu_lib(), case, xdt, ydt)
