@@ -10,7 +10,8 @@ from lama_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-from tests.test_kernels_emu import CONV_CASES, CONV_TOL, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_ref, _inv_ref, _spec_ref  # noqa: E402
+from tests.test_kernels_emu import (CONV_CASES, CONV_TOL, F16_CASES, F16_STEM_HEAD, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_f16_ref, _conv_ref,  # noqa: E402
+                                    _inv_ref, _spec_ref)
 
 
 @pytest.fixture(scope='module')
@@ -379,3 +380,83 @@ def test_overlap_streams_bit_identical():
         gen._plans.clear()
         for _ in range(25):
             assert torch.equal(gen(x), ref), graph
+
+
+def _run_f16_case_gpu(lib, case, x_dtype=torch.float16, y_dtype=torch.float16, B=2):
+    g = torch.Generator().manual_seed(3)
+    cin, cout, k = case['cin'], case['cout'], case['k']
+    tr = case.get('transposed', False)
+    x = torch.randn(B, cin, case['H'], case['W'], generator=g).to(x_dtype)
+    w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * (case.get('wscale') or 0.2)
+    scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
+    bias = torch.randn(cout, generator=g) if case['bias'] else None
+    ref0 = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
+    resid = torch.randn(ref0.shape, generator=g).to(y_dtype) if case['resid'] else None
+    ref = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
+    wp = lib.pack_conv_weight(w.to(DEV), None if scale is None else scale.to(DEV), stride=case['stride'], transposed=tr, precision=L.PREC_F16)
+    ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0, dtype=y_dtype, device=DEV)
+    xd = x.to(DEV)
+    rd = None if resid is None else resid.to(DEV)
+    bd = None if bias is None else bias.to(DEV)
+    lib.conv2d(L.view(xd), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'], L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bd,
+               case['act'], None if rd is None else L.view(rd), precision=L.PREC_F16, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    y = ybuf[:, 2:2 + cout].float().cpu()
+    tol = 2e-3 * max(1.0, float(ref.abs().max())) if y_dtype == torch.float16 else 2e-4 * max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) < tol, float((y - ref).abs().max())
+    assert float(ybuf[:, :2].float().min()) == 7.0 and float(ybuf[:, -1].float().max()) == 7.0
+
+
+@pytest.mark.parametrize('case', F16_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d_fp16_io(anylib, case):
+    """LAMA_PREC_F16 (BASELINE configs[2]): fp16 tensors, one product per MAC -- every kernel family, production selection and forced."""
+    _run_f16_case_gpu(anylib, case)
+
+
+@pytest.mark.parametrize('case,xdt,ydt', F16_STEM_HEAD, ids=['stem_f32_to_f16', 'head_f16_to_f32'])
+def test_conv2d_fp16_stem_head(anylib, case, xdt, ydt):
+    _run_f16_case_gpu(anylib, case, xdt, ydt)
+
+
+F16_BIG = [
+    dict(cin=512, cout=128, k=3, stride=1, pad=1, H=64, W=64, act=1, bias=True, resid=True, scale=True, wscale=0.02),     # local conv (wreg 4 x 2)
+    dict(cin=384, cout=192, k=1, stride=1, pad=0, H=64, W=64, act=1, bias=True, resid=False, scale=True, wscale=0.05),    # conv1 (persistent GEMM)
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=64, W=33, act=1, bias=True, resid=False, scale=True, wscale=0.05),    # spectral GEMM
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=128, W=128, act=1, bias=True, resid=False, scale=True, wscale=0.05),   # downsample
+    dict(cin=256, cout=128, k=3, stride=2, pad=1, H=32, W=48, act=1, bias=True, resid=False, scale=True, wscale=0.03, transposed=True),
+]
+
+
+@pytest.mark.parametrize('case', F16_BIG, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d_fp16_io_full_size(lib, case):
+    _run_f16_case_gpu(lib, case)
+
+
+def test_conv2d_fp16_stem_head_full_size(lib):
+    """the dedicated stem / head kernels (production thresholds) at the ends of the fp16 path"""
+    _run_f16_case_gpu(lib, dict(cin=4, cout=64, k=7, stride=1, pad=3, H=512, W=256, act=1, bias=True, resid=False, scale=True, wscale=0.1),
+                      torch.float32, torch.float16)
+    _run_f16_case_gpu(lib, dict(cin=64, cout=3, k=7, stride=1, pad=3, H=512, W=416, act=2, bias=True, resid=False, scale=False, wscale=0.03),
+                      torch.float16, torch.float32)
+
+
+@pytest.mark.parametrize('hw', [(64, 64), (128, 128), (32, 32), (256, 256), (24, 40)], ids=lambda s: f'{s[0]}x{s[1]}')
+def test_rfft2_irfft2_fp16_io(lib, hw):
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 7 + w)
+    B, Cn = 2, 8
+    x = torch.randn(B, Cn, h, w, generator=g).half()
+    xd = x.to(DEV)
+    spec = torch.zeros(B, 2 * Cn, h, w // 2 + 1, dtype=torch.float16, device=DEV)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rfft2(L.view(xd), L.view(spec), B, ws, stream=st)
+    ref = _spec_ref(x.float())
+    assert torch.allclose(spec.float().cpu(), ref, atol=2e-3 * float(ref.abs().max()), rtol=2e-3)
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g)).half()
+    resid = torch.randn(B, Cn, h, w, generator=g).half()
+    y = torch.zeros(B, Cn, h, w, dtype=torch.float16, device=DEV)
+    s2d, rd = spec2.to(DEV), resid.to(DEV)
+    lib.irfft2(L.view(s2d), L.view(rd), L.view(y), B, ws, stream=st)
+    ref2 = resid.float() + _inv_ref(spec2.float(), h, w)
+    assert torch.allclose(y.float().cpu(), ref2, atol=4e-3, rtol=2e-3)
