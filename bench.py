@@ -266,7 +266,7 @@ def configs2_leg(model, device, lib, args):
         out[name] = dict(value=round(4 / dt, 2), unit='images/s', ms_per_step=round(dt * 1e3, 3), steps=n)
         model.generator._plans.clear()
     out['workload'] = 'big-lama 1024x1024 batch=4, mask-compose + generator + blend + u8, hipGraph replay'
-    out['dtype_f16'] = 'fp16 activations in HBM, fp16 weights, 1 MFMA product per MAC, fp32 accumulate (tolerance 5e-3 vs the fp32 oracle)'
+    out['dtype_f16'] = 'fp16 activations in HBM (fp32 residual stream), fp16 weights, 1 MFMA product per MAC, fp32 accumulate; measured 1.0e-2 max-abs vs the fp32 oracle at 4x1024^2 = the level of fp16-rounded operands in the oracle itself (tests hold 2e-2)'
     torch.cuda.empty_cache()
     return out
 

@@ -135,6 +135,9 @@ class RearPass:
     def __init__(self, generator: F.FFCResNetGenerator, first: int, bwd_precision: int = L.PREC_BF16X3):
         if bwd_precision == L.PREC_F16X3:
             raise LamaError('the reverse pass does not run on the fp16 split (gradients underflow its lo term): use bf16x3 or f32')
+        if bwd_precision == L.PREC_F16 or generator.precision == L.PREC_F16:
+            raise LamaError('refinement runs on fp32 activation tensors: set the generator to f16x3 / bf16x3 / f32 (the tape and the '
+                            'gradients are fp32; LAMA_PREC_F16 is the plain predict path only)')
         self.gen, self.ex, self.bprec = generator, generator._exec, bwd_precision
         layers = list(generator.model)[first:]
         self.blocks: List[tuple] = []

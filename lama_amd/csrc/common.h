@@ -111,4 +111,5 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
     int lama_cb_conv2d_fwd##sfx(hipStream_t stream, const lama_conv2d_args* a, int Ho, int Wo);
 LAMA_CB_DECL(_bf16x3)
 LAMA_CB_DECL(_f16x3)
+LAMA_CB_DECL(_f16)
 #undef LAMA_CB_DECL

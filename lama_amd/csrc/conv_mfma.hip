@@ -476,7 +476,8 @@ extern "C" int lama_conv2d_fwd(void* stream, const lama_conv2d_args* a) {
     {   // element types: fp16 tensors only with LAMA_PREC_F16 (and LAMA_PREC_F16 only with them: at least x or y is fp16)
         const bool xh = a->x.dtype == LAMA_DT_F16, yh = a->y.dtype == LAMA_DT_F16;
         if ((a->x.dtype != LAMA_DT_F32 && !xh) || (a->y.dtype != LAMA_DT_F32 && !yh)) return LAMA_ERR_BAD_ARG;
-        if (a->x2.ptr && a->x2.dtype != a->x.dtype) return LAMA_ERR_BAD_ARG;
+        if (a->x2.ptr && a->x2.dtype != LAMA_DT_F32 && a->x2.dtype != LAMA_DT_F16) return LAMA_ERR_BAD_ARG;
+        if (a->x2.ptr && a->x2.dtype == LAMA_DT_F16 && a->precision != LAMA_PREC_F16) return LAMA_ERR_UNSUPPORTED;
         if (a->resid.ptr && a->resid.dtype != a->y.dtype) return LAMA_ERR_BAD_ARG;
         if ((xh || yh) != (a->precision == LAMA_PREC_F16)) return LAMA_ERR_UNSUPPORTED;
     }
@@ -497,7 +498,8 @@ extern "C" int lama_conv2d_fwd(void* stream, const lama_conv2d_args* a) {
     if (has2 && (a->transposed || !a->w2_packed || a->x2.H != Ho || a->x2.W != Wo || !tensor_ok(a->x2))) return LAMA_ERR_BAD_ARG;
     if (a->resid.ptr && (a->resid.C != cout || a->resid.H != Ho || a->resid.W != Wo)) return LAMA_ERR_BAD_ARG;
     if (a->precision == LAMA_PREC_BF16X3) return lama_cb_conv2d_fwd_bf16x3((hipStream_t)stream, a, Ho, Wo);
-    if (a->precision == LAMA_PREC_F16X3 || a->precision == LAMA_PREC_F16) return lama_cb_conv2d_fwd_f16x3((hipStream_t)stream, a, Ho, Wo);
+    if (a->precision == LAMA_PREC_F16X3) return lama_cb_conv2d_fwd_f16x3((hipStream_t)stream, a, Ho, Wo);
+    if (a->precision == LAMA_PREC_F16) return lama_cb_conv2d_fwd_f16((hipStream_t)stream, a, Ho, Wo);
 
     ConvPlan pl2;
     if (has2 && !make_plan(cout, a->x2.C, 1, 1, 1, 0, 0, &pl2)) return LAMA_ERR_UNSUPPORTED;

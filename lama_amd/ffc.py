@@ -494,7 +494,9 @@ class FFC_BN_ACT(_HipModule):
         src, cl, cg = _pair_buffer(x_l, x_g)
         if cl != self.ffc.in_cl or cg != self.ffc.in_cg:
             raise LamaError(f'FFC_BN_ACT expected ({self.ffc.in_cl},{self.ffc.in_cg}) local/global channels, got ({cl},{cg})')
-        dst = torch.empty(self.out_shape(src.shape, extra_pad), device=src.device, dtype=_act_dtype(self.precision))
+        # a layer with a global output produces the (x_l | x_g) state of the resnet blocks: fp32 at every precision (see _build_plan)
+        dst = torch.empty(self.out_shape(src.shape, extra_pad), device=src.device,
+                          dtype=torch.float32 if self.ffc.out_cg else _act_dtype(self.precision))
         with self._exec.range_scope(src, self.precision):
             self.run(src, dst, self.make_scratch(src.shape, src.device), None, extra_pad)
         ocl, ocg = self.ffc.out_cl, self.ffc.out_cg
@@ -523,7 +525,7 @@ class FFCResnetBlock(_HipModule):
         x_l, x_g = x if type(x) is tuple else (x, 0)
         self._exec.check(x_l)
         src, cl, cg = _pair_buffer(x_l, x_g)
-        tmp, dst = torch.empty_like(src), torch.empty_like(src)
+        tmp, dst = torch.empty_like(src, dtype=_act_dtype(self.precision)), torch.empty_like(src)   # the state keeps its element type
         with self._exec.range_scope(src, self.precision):
             self.run(src, tmp, dst, self.conv1.make_scratch(src.shape, src.device))
         return (dst[:, :cl], dst[:, cl:]) if cg else (dst, 0)
@@ -772,9 +774,13 @@ class FFCResNetGenerator(_HipModule):
         i, n = 0, len(layers)
         pad_pending = 0
 
-        def new(name, shp):
-            # PREC_F16: every activation between the stem's output and the head's input is fp16; the image that leaves the head is fp32
-            bufs[name] = torch.empty(shp, device=device, dtype=torch.float32 if name == 'out' else _act_dtype(self.precision))
+        adt = _act_dtype(self.precision)
+
+        def new(name, shp, dtype=None):
+            # PREC_F16: the activations between the stem's output and the head's input are fp16, EXCEPT the residual stream of the
+            # resnet blocks (the (x_l | x_g) state that every block adds to: 18 fp16 roundings of it cost 2x the end-to-end error);
+            # the image that leaves the head is fp32
+            bufs[name] = torch.empty(shp, device=device, dtype=dtype or adt)
             return name
 
         scratch = None
@@ -785,13 +791,14 @@ class FFCResNetGenerator(_HipModule):
                 pad_pending = lay.padding; i += 1; continue
             if isinstance(lay, FFC_BN_ACT):
                 shp = lay.out_shape(cur_shape, pad_pending)
-                dst = new(f'a{k}', shp); k += 1
+                feeds_blocks = lay.ffc.out_cg > 0      # the layer that produces the first (x_l | x_g) state
+                dst = new(f'a{k}', shp, torch.float32 if feeds_blocks else None); k += 1
                 steps.append(('ffc', lay, cur, dst, pad_pending))
                 cur, cur_shape, pad_pending = dst, shp, 0
             elif isinstance(lay, FFCResnetBlock):
                 if scratch is None:
                     scratch = lay.conv1.make_scratch(cur_shape, device)
-                    new('rt', cur_shape); new('rA', cur_shape); new('rB', cur_shape)
+                    new('rt', cur_shape); new('rA', cur_shape, torch.float32); new('rB', cur_shape, torch.float32)
                 dst = 'rA' if cur != 'rA' else 'rB'
                 steps.append(('res', lay, cur, 'rt', dst))
                 cur = dst
@@ -813,7 +820,7 @@ class FFCResNetGenerator(_HipModule):
                 B, _, H, W = cur_shape
                 kk, p = lay.kernel_size[0], lay.padding[0] + pad_pending
                 shp = (B, lay.out_channels, H + 2 * p - kk + 1, W + 2 * p - kk + 1)
-                dst = new('out', shp)
+                dst = new('out', shp, torch.float32)
                 steps.append(('out', lay, cur, dst, pad_pending, _ACT[act.kind] if act else L.ACT_NONE))
                 cur, cur_shape, pad_pending = dst, shp, 0
                 if act:

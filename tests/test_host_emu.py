@@ -175,8 +175,9 @@ def test_f16_split_overflow_falls_back_to_bf16x3():
 
 def test_generator_fp16_activation_path(small):
     """BASELINE configs[2] "fp16" = PREC_F16: fp16 activations in memory between the stem and the head, fp16 weights, one MFMA
-    product per MAC, fp32 accumulation.  Tolerance 5e-3 max-abs on the sigmoid output (the fp32-class paths are
-    held to 2e-4), and the layer-by-layer Sequential agrees with the fused plan."""
+    product per MAC, fp32 accumulation.  Tolerance: 5e-3 max-abs on the sigmoid output at this size and no worse than 1.5x the error
+    of the oracle run with fp16-rounded conv operands (the fp32-class paths are held to 2e-4); the layer-by-layer Sequential agrees
+    with the fused plan."""
     from lama_amd import _lib as L
     cfg, sd, gen = small
     batch = O.make_synthetic_batch(2, 64, 64, seed=9)
@@ -186,11 +187,16 @@ def test_generator_fp16_activation_path(small):
     gen.set_precision(L.PREC_F16)
     try:
         y = gen(x)
-        assert y.dtype == torch.float32 and float((y - ref).abs().max()) < 5e-3, float((y - ref).abs().max())
+        with torch.no_grad():
+            emu_err = float((O.generator_forward_fp16_emulated(x, sd, cfg) - ref).abs().max())
+        err = float((y - ref).abs().max())
+        assert y.dtype == torch.float32 and err < 5e-3 and err < 1.5 * emu_err, (err, emu_err)
         plan = next(iter(gen._plans.values()))
-        assert all(b.dtype == torch.float16 for n, b in plan['bufs'].items() if n != 'out') and plan['bufs']['out'].dtype == torch.float32
+        f32 = sorted(n for n, b in plan['bufs'].items() if b.dtype == torch.float32)
+        assert all(b.dtype in (torch.float16, torch.float32) for b in plan['bufs'].values())
+        assert 'out' in f32 and 'rA' in f32 and 'rB' in f32 and len(f32) <= 4, f32     # the residual stream (and what feeds it) stays fp32
         z = gen.model[0:5](x)
-        assert z[0].dtype == torch.float16
+        assert z[0].dtype == torch.float32                                            # ... also layer by layer
         y2 = gen.model[5:](z)
         assert float((y2 - y).abs().max()) < 1e-6
     finally:

@@ -351,9 +351,9 @@ def _run_f16_case(lib, case, x_dtype=torch.float16, y_dtype=torch.float16):
     w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.2
     scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
     bias = torch.randn(cout, generator=g) if case['bias'] else None
-    ref0 = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
+    ref0 = _conv_f16_ref(x.half(), w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
     resid = torch.randn(ref0.shape, generator=g).to(y_dtype) if case['resid'] else None
-    ref = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
+    ref = _conv_f16_ref(x.half(), w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)   # fp32 inputs are rounded once
     wp = lib.pack_conv_weight(w, scale, stride=case['stride'], transposed=tr, precision=L.PREC_F16)
     ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0, dtype=y_dtype)
     lib.conv2d(L.view(x), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'], L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
@@ -369,24 +369,48 @@ def test_conv2d_fp16_io_emulated(case):
     _run_f16_case(emu_lib(), case)
 
 
+# LAMA_PREC_F16 keeps the resnet blocks' residual stream in fp32: the launches that read or write it mix
+# element types -- (x dtype, y/resid dtype); every kernel family has to take both directions or fall through to one that does
+F16_MIXED = [
+    dict(cin=64, cout=130, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True),         # weights-in-registers, local
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=False, scale=True),         # persistent GEMM (conv1)
+    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=1, bias=True, resid=True, scale=True),         # ... with a residual: falls through
+    dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),         # 1x1 wreg shape: falls through
+    dict(cin=8, cout=16, k=3, stride=2, pad=1, H=16, W=24, act=1, bias=True, resid=False, scale=True),          # LDS-staged, the last downsample
+    dict(cin=12, cout=40, k=3, stride=1, pad=1, H=9, W=7, act=0, bias=False, resid=True, scale=False),
+    dict(cin=24, cout=70, k=3, stride=2, pad=1, H=9, W=34, act=1, bias=True, resid=False, scale=True, transposed=True),   # first upsample
+]
+
+
+@pytest.mark.parametrize('xdt,ydt', [(torch.float32, torch.float16), (torch.float16, torch.float32)], ids=['f32_to_f16', 'f16_to_f32'])
+@pytest.mark.parametrize('case', F16_MIXED, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d_fp16_mixed_io_emulated(case, xdt, ydt):
+    _run_f16_case(emu_lib(), case, xdt, ydt)
+
+
+@pytest.mark.parametrize('sdt,odt', [(torch.float16, torch.float16), (torch.float32, torch.float16), (torch.float16, torch.float32)],
+                         ids=['f16', 'state_f32', 'out_f32'])
 @pytest.mark.parametrize('cg_', [160, 384], ids=['cg160', 'cg384'])
-def test_conv2d_fp16_fused_second_operand_wreg_emulated(cg_):
-    """The bottleneck global-branch launch (3x3 over x_l + 1x1 over t + bias + ReLU + residual) with fp16 activations."""
+def test_conv2d_fp16_fused_second_operand_wreg_emulated(cg_, sdt, odt):
+    """The bottleneck global-branch launch (3x3 over x_l + 1x1 over t + bias + ReLU + residual) with fp16 activations; the block's
+    first layer reads the fp32 residual stream (state fp32, t and the output fp16), its second layer writes it (x and t fp16, the
+    residual and the output fp32)."""
     lib = emu_lib()
     g = torch.Generator().manual_seed(3)
     B, cl, cg, half, H, W = 2, 32, cg_, 64, 6, 35
-    state = torch.randn(B, cl + cg, H, W, generator=g).half()
+    state = torch.randn(B, cl + cg, H, W, generator=g).to(sdt)
     t = torch.randn(B, half, H, W, generator=g).half()
     w1 = torch.randn(cg, cl, 3, 3, generator=g) * 0.2
     w2 = torch.randn(cg, half, 1, 1, generator=g) * 0.2
     scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
-    ref = _conv_f16_ref(state[:, :cl], w1, 1, 1, True, False, bias, 1, state[:, cl:], x2=t, w2=w2, scale=scale)
-    out = torch.zeros_like(state)
+    resid = torch.randn(B, cg, H, W, generator=g).to(odt)
+    ref = _conv_f16_ref(state[:, :cl].half(), w1, 1, 1, True, False, bias, 1, resid, x2=t, w2=w2, scale=scale)
+    out = torch.zeros(B, cl + cg, H, W, dtype=odt)
     lib.conv2d(L.view(state, 0, cl), lib.pack_conv_weight(w1, scale, precision=L.PREC_F16), L.view(out, cl, cg), B, 3, 1, 1, L.PAD_REFLECT,
-               False, bias, L.ACT_RELU, L.view(state, cl, cg), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale, precision=L.PREC_F16),
+               False, bias, L.ACT_RELU, L.view(resid), x2=L.view(t), w2_packed=lib.pack_conv_weight(w2, scale, precision=L.PREC_F16),
                precision=L.PREC_F16)
     err = float((out[:, cl:].float() - ref).abs().max())
-    assert err < 2e-3 * max(1.0, float(ref.abs().max())), err
+    assert err < (2e-3 if odt == torch.float16 else 1e-4) * max(1.0, float(ref.abs().max())), err
     assert float(out[:, :cl].float().abs().max()) == 0.0
 
 

@@ -10,7 +10,7 @@ from lama_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-from tests.test_kernels_emu import (CONV_CASES, CONV_TOL, F16_CASES, F16_STEM_HEAD, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_f16_ref, _conv_ref,  # noqa: E402
+from tests.test_kernels_emu import (CONV_CASES, CONV_TOL, F16_CASES, F16_MIXED, F16_STEM_HEAD, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_f16_ref, _conv_ref,  # noqa: E402
                                     _inv_ref, _spec_ref)
 
 
@@ -390,9 +390,9 @@ def _run_f16_case_gpu(lib, case, x_dtype=torch.float16, y_dtype=torch.float16, B
     w = torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * (case.get('wscale') or 0.2)
     scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
     bias = torch.randn(cout, generator=g) if case['bias'] else None
-    ref0 = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
+    ref0 = _conv_f16_ref(x.half(), w, case['stride'], case['pad'], True, tr, None, 0, None, scale=scale)
     resid = torch.randn(ref0.shape, generator=g).to(y_dtype) if case['resid'] else None
-    ref = _conv_f16_ref(x, w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
+    ref = _conv_f16_ref(x.half(), w, case['stride'], case['pad'], True, tr, bias, case['act'], resid, scale=scale)
     wp = lib.pack_conv_weight(w.to(DEV), None if scale is None else scale.to(DEV), stride=case['stride'], transposed=tr, precision=L.PREC_F16)
     ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0, dtype=y_dtype, device=DEV)
     xd = x.to(DEV)
@@ -418,6 +418,40 @@ def test_conv2d_fp16_stem_head(anylib, case, xdt, ydt):
     _run_f16_case_gpu(anylib, case, xdt, ydt)
 
 
+MIXED_IO = [(torch.float32, torch.float16), (torch.float16, torch.float32)]
+
+
+@pytest.mark.parametrize('xdt,ydt', MIXED_IO, ids=['f32_to_f16', 'f16_to_f32'])
+@pytest.mark.parametrize('case', F16_MIXED, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
+def test_conv2d_fp16_mixed_io(anylib, case, xdt, ydt):
+    """LAMA_PREC_F16 launches next to the fp32 residual stream of the resnet blocks."""
+    _run_f16_case_gpu(anylib, case, xdt, ydt)
+
+
+@pytest.mark.parametrize('sdt,odt', [(torch.float16, torch.float16)] + MIXED_IO, ids=['f16', 'state_f32', 'out_f32'])
+@pytest.mark.parametrize('hw', [(6, 35), (64, 64)], ids=['6x35', '64x64'])
+def test_conv2d_fp16_fused_second_operand(anylib, hw, sdt, odt):
+    """The bottleneck global-branch launch at LAMA_PREC_F16 in the three element-type mixes the generator plan uses."""
+    g = torch.Generator().manual_seed(3)
+    B, cl, cg, half, (H, W) = 2, 128, 384, 192, hw
+    state = torch.randn(B, cl + cg, H, W, generator=g).to(sdt)
+    t = torch.randn(B, half, H, W, generator=g).half()
+    w1, w2 = torch.randn(cg, cl, 3, 3, generator=g) * 0.03, torch.randn(cg, half, 1, 1, generator=g) * 0.05
+    scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
+    resid = torch.randn(B, cg, H, W, generator=g).to(odt)
+    ref = _conv_f16_ref(state[:, :cl].half(), w1, 1, 1, True, False, bias, 1, resid, x2=t, w2=w2, scale=scale)
+    out = torch.zeros(B, cl + cg, H, W, dtype=odt, device=DEV)
+    sd_, td, rd, sc = state.to(DEV), t.to(DEV), resid.to(DEV), scale.to(DEV)
+    anylib.conv2d(L.view(sd_, 0, cl), anylib.pack_conv_weight(w1.to(DEV), sc, precision=L.PREC_F16), L.view(out, cl, cg), B, 3, 1, 1,
+                  L.PAD_REFLECT, False, bias.to(DEV), L.ACT_RELU, L.view(rd), x2=L.view(td),
+                  w2_packed=anylib.pack_conv_weight(w2.to(DEV), sc, precision=L.PREC_F16), precision=L.PREC_F16,
+                  stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    err = float((out[:, cl:].float().cpu() - ref).abs().max())
+    assert err < (2e-3 if odt == torch.float16 else 2e-4) * max(1.0, float(ref.abs().max())), err
+    assert float(out[:, :cl].float().abs().max()) == 0.0
+
+
 F16_BIG = [
     dict(cin=512, cout=128, k=3, stride=1, pad=1, H=64, W=64, act=1, bias=True, resid=True, scale=True, wscale=0.02),     # local conv (wreg 4 x 2)
     dict(cin=384, cout=192, k=1, stride=1, pad=0, H=64, W=64, act=1, bias=True, resid=False, scale=True, wscale=0.05),    # conv1 (persistent GEMM)
@@ -430,6 +464,14 @@ F16_BIG = [
 @pytest.mark.parametrize('case', F16_BIG, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
 def test_conv2d_fp16_io_full_size(lib, case):
     _run_f16_case_gpu(lib, case)
+
+
+@pytest.mark.parametrize('xdt,ydt', MIXED_IO, ids=['f32_to_f16', 'f16_to_f32'])
+@pytest.mark.parametrize('case', [F16_BIG[0], F16_BIG[1], F16_BIG[3], F16_BIG[4]], ids=['local', 'conv1', 'down', 'up'])
+def test_conv2d_fp16_mixed_io_full_size(lib, case, xdt, ydt):
+    if case is F16_BIG[1] and ydt == torch.float32:
+        case = dict(case, resid=True)
+    _run_f16_case_gpu(lib, case, xdt, ydt)
 
 
 def test_conv2d_fp16_stem_head_full_size(lib):
