@@ -294,6 +294,7 @@ static inline void hipemu_buf_store_b16(lama_buf_t r, unsigned short v, unsigned
 #define LAMA_WAVE_UNIFORM(x) (x)
 #define LAMA_WAVE_SYNC() hipemu::wave_barrier()
 #define LAMA_CLOCK() 0ll
+#define LAMA_CYCLES() 0ll
 
 // math helpers that exist in HIP device code
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }

@@ -44,5 +44,10 @@ ch = (rel[:, 2:2 + nch] - rel[:, 1:1 + nch])
 print('chunks  : median per chunk ' + ' '.join(f'{v:.2f}' for v in ch.median(0).values.tolist()))
 print(f'epilogue: median {(rel[:, 30] - last).median():.2f} max {(rel[:, 30] - last).max():.2f}')
 print(f'workgroup total: median {end.median():.2f} max {end.max():.2f}; last end {rel[:, 30].max():.2f}')
+if name == 'convA' and int(t[:, 18].max()) > 0:   # shader-clock stamps of the k-steps of chunk 8 (wave 0 of every workgroup)
+    ks = (t[:, 19:29] - t[:, 18:28]).double()
+    print('chunk 8, k-steps 0..8 + barrier + stamp store (shader clocks, median over workgroups): ' + ' '.join(f'{v:.0f}' for v in ks.median(0).values.tolist()))
+    tot = (t[:, 27] - t[:, 18]).double().median()
+    print(f'chunk 8 k-steps total {tot:.0f} shader clocks; same chunk on the 100 MHz clock {ch[:, 8].median():.2f} us')
 late = t[start > start.median() + 1.0].shape[0]
 print(f'workgroups starting > 1 us after the median start (second round): {late}')
