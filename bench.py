@@ -214,6 +214,39 @@ def cpu_one_thread_leg():
     print(json.dumps(dict(images_per_s=round(1.0 / dt, 4), images=1, threads=torch.get_num_threads(), seconds=round(dt, 1))), flush=True)
 
 
+def sustained_mfma_peak(device, seconds=0.25):
+    """Dense f16 MFMA rate THIS box sustains on random operands (nothing but v_mfma_f32_32x32x16_f16 on register operands that change
+    with every instruction: lama_debug_mfma_peak in the profiling build of the library, csrc/debug_probes.hip).  The part is power
+    limited: all-zero data reach ~98 % of the 2.5 PF spec, random data 67-71 % -- measured here, live."""
+    import ctypes as C
+    path = os.path.join(ROOT, 'lama_amd', 'lib', 'liblama_hip_prof.so')
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = C.CDLL(path)
+        fn = lib.lama_debug_mfma_peak
+        fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        g = torch.Generator().manual_seed(7)
+        data = (torch.randn(4096 * 8, generator=g) * 1.5).half().to(device)
+        st = torch.cuda.current_stream().cuda_stream
+        if fn(st, 2000, data.data_ptr(), None) != 0:
+            return None
+        torch.cuda.synchronize()
+        iters = 200000
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn(st, iters, data.data_ptr(), None)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        tf = 256 * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12
+        return dict(value=round(tf, 1), unit='TFLOP/s dense f16', seconds=round(ms * 1e-3, 3),
+                    how='lama_debug_mfma_peak (liblama_hip_prof.so): 256 workgroups x 4 waves, 4 A x 4 B random register fragments per wave, '
+                        'v_mfma_f32_32x32x16_f16 only')
+    except Exception as e:      # measurement extra: never fail the bench
+        return dict(error=str(e))
+
+
 def eager_leg(steps=5):
     """Child of main(): BASELINE configs[1]'s comparator -- the same generator as PyTorch-ROCm EAGER ops on this GPU (torch conv2d /
     conv_transpose2d = MIOpen, batch_norm, torch.fft.rfftn / irfftn = rocFFT), i.e. the oracle's functional restatement of the
@@ -403,6 +436,11 @@ def main():
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
                              'algorithmic product; achieved counts algorithmic FLOPs only')
+            if precision != L.PREC_F32:
+                sus = sustained_mfma_peak(device)
+                if sus and sus.get('value'):
+                    roof['peak_sustained'] = sus
+                    roof['frac_of_sustained'] = round(ach / (sus['value'] / 3.0), 4)
         fu = next((k for k in kern if k.startswith('fourier_unit')), None)
         if fu:
             alg = 2 * BATCH * 192 * h * h * 4 + 384 * 384 * 4 + 384 * 4       # read x, write y, weights once

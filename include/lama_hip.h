@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 102
+#define LAMA_HIP_VERSION 103
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -187,6 +187,15 @@ int lama_l1_masked_bwd(void* stream, const lama_tensor* pred, const lama_tensor*
  * step = 1, 2, ... */
 int lama_adam_step(void* stream, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                    float beta2, float eps, int32_t step);
+
+/* ---- quality metrics --------------------------------------------------------------------------
+ * SSIM.forward(img1, img2) with size_average=False (saicinpainting/evaluation/losses/ssim.py:18-71): out[i] = mean over (C, H, W)
+ * of the SSIM map of image i; depthwise window_size x window_size gaussian window given as its normalised 1-D factor `window1d`
+ * (HOST array of window_size floats, ssim.py:36-45), zero padding window_size / 2.  Odd window sizes up to 15.  workspace: device
+ * scratch of lama_ssim_workspace_bytes() bytes.  Replaces the five F.conv2d(groups=channel) calls + the elementwise map. */
+size_t lama_ssim_workspace_bytes(int32_t batch, int32_t C, int32_t H, int32_t W);
+int lama_ssim_fwd(void* stream, const lama_tensor* img1, const lama_tensor* img2, int32_t batch, int32_t window_size,
+                  const float* window1d, float* out, void* workspace, size_t workspace_bytes);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 102      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 103      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -114,6 +114,8 @@ class LamaLib:
                            ('lama_adam_step', [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32])):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = C.c_int, args
+        L.lama_ssim_workspace_bytes.restype, L.lama_ssim_workspace_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
+        L.lama_ssim_fwd.restype, L.lama_ssim_fwd.argtypes = C.c_int, [vp, T, T, i32, i32, C.POINTER(C.c_float), vp, vp, C.c_size_t]
         del dp
         if L.lama_version() != ABI_VERSION:
             raise LamaError(f'{path}: ABI version {L.lama_version()} != {ABI_VERSION}')
@@ -232,6 +234,18 @@ class LamaLib:
     def reflect_pad_bwd(self, gp: Tensor4, addend: Optional[Tensor4], pad: int, g: Tensor4, batch: int, stream: int = 0):
         self.check(self._l.lama_reflect_pad_bwd(stream, C.byref(gp), None if addend is None else C.byref(addend), pad, C.byref(g), batch),
                    'lama_reflect_pad_bwd')
+
+    def ssim(self, img1: Tensor4, img2: Tensor4, batch: int, window1d, out: torch.Tensor, workspace: torch.Tensor, stream: int = 0):
+        """Per-image SSIM (ssim.py:46-71, size_average=False) into out [batch] fp32; window1d = host sequence of the odd-length
+        normalised 1-D gaussian; workspace = device buffer of at least ssim_workspace_bytes() bytes."""
+        if not self.host_emulated and not (out.is_cuda and workspace.is_cuda):
+            raise LamaError('ssim: out / workspace must be device tensors')
+        w = (C.c_float * len(window1d))(*[float(v) for v in window1d])
+        self.check(self._l.lama_ssim_fwd(stream, C.byref(img1), C.byref(img2), batch, len(window1d), w, out.data_ptr(), workspace.data_ptr(),
+                                         workspace.numel() * workspace.element_size()), 'lama_ssim_fwd')
+
+    def ssim_workspace_bytes(self, batch: int, c: int, h: int, w: int) -> int:
+        return int(self._l.lama_ssim_workspace_bytes(batch, c, h, w))
 
     def gauss5(self, x: Tensor4, y: Tensor4, batch: int, stream: int = 0):
         self.check(self._l.lama_gauss5_fwd(stream, C.byref(x), C.byref(y), batch), 'lama_gauss5_fwd')

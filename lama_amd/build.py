@@ -20,7 +20,7 @@ LIB = os.path.join(LIBDIR, 'liblama_hip.so')
 # Same sources with -DLAMA_PROFILING: kernel-selection overrides, timing ablations and timeline tracers read from the environment.
 # Only tools/ and the forced-path GPU tests load it (LAMA_HIP_LIB / LamaLib(path)); the product never does.
 LIB_PROF = os.path.join(LIBDIR, 'liblama_hip_prof.so')
-SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'conv_f16.hip', 'fft.hip', 'elementwise.hip', 'refine.hip']
+SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'conv_f16.hip', 'fft.hip', 'elementwise.hip', 'refine.hip', 'metrics.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'),
            os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
 # Every translation unit is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).

@@ -133,3 +133,41 @@ extern "C" int lama_debug_hog(void* stream, int32_t grid, int32_t mode, int32_t 
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Sustained MFMA ceiling of THIS box (bench.py's roofline.peak_sustained; stand-alone version: tools/ubench/mfma_power.hip): one
+// 256-thread workgroup per CU, every wave keeps 4 A and 4 B fragments of the caller's data in registers and issues
+// v_mfma_f32_32x32x16_f16 over all 16 pairs, so the operands change with every instruction and nothing else runs.  On MI355X the
+// rate depends on the DATA (power): all-zero operands reach 98 % of the 2.5 PF spec, random operands 67-71 %.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void debug_mfma_peak_kernel(int iters, const uint4* in, float* out) {
+    typedef float f32x16_t __attribute__((ext_vector_type(16)));
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f16x8_t a[4], b[4];
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(f16x8_t, in[((wave * 8 + i) * 64 + lane) & 4095]);
+        b[i] = __builtin_bit_cast(f16x8_t, in[((wave * 8 + 4 + i) * 64 + lane) & 4095]);
+    }
+    f32x16_t acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[j], 0, 0, 0);
+    }
+    float s = 0.0f;
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (out) out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// in: 4096 x 16 bytes of fp16 operand data (device), out: 256 * 256 floats (device) or NULL; 256 workgroups x iters x 16 MFMAs per wave,
+// 4 waves per workgroup -> flops = 256 * 4 * iters * 16 * 32768
+extern "C" int lama_debug_mfma_peak(void* stream, int32_t iters, const void* in, float* out) {
+    hipLaunchKernelGGL(debug_mfma_peak_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, iters, (const uint4*)in, out);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}

@@ -305,5 +305,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 // ---- launch --------------------------------------------------------------------------------
 template <class K, class... Args>
 static inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t /*shmem*/, hipStream_t, Args... args) {
+    static const bool trace = std::getenv("HIPEMU_TRACE") != nullptr;   // which launch geometry did the host code pick?
+    if (trace) std::fprintf(stderr, "[hipemu] launch grid=%u block=%u args=%zu bytes\n", grid.x, block.x, (sizeof(Args) + ... + 0));
     hipemu::run_grid(grid, block, [=]() { kernel(args...); });
 }

@@ -49,6 +49,9 @@ CONV_CASES = [
     dict(cin=32, cout=96, k=3, stride=1, pad=1, H=5, W=6, act=0, bias=False, resid=False, scale=False),    # one chunk, narrow image
     dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),    # flat 1x1, two chunks
     dict(cin=192, cout=200, k=1, stride=1, pad=0, H=12, W=11, act=2, bias=True, resid=False, scale=False),  # odd chunk count
+    # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
+    dict(cin=32, cout=128, k=3, stride=2, pad=1, H=16, W=70, act=1, bias=True, resid=False, scale=True),
+    dict(cin=64, cout=200, k=3, stride=2, pad=1, H=11, W=37, act=0, bias=False, resid=True, scale=False),
     # full-M 1x1 workgroups: 384 rows = 12 M-waves, 192 rows = 6 M-waves x 2 K-groups (K-group exchange + one residual set)
     dict(cin=128, cout=384, k=1, stride=1, pad=0, H=5, W=33, act=1, bias=True, resid=True, scale=True),
     dict(cin=192, cout=192, k=1, stride=1, pad=0, H=9, W=16, act=1, bias=True, resid=True, scale=True),
@@ -325,6 +328,7 @@ F16_CASES = [
     dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),
     dict(cin=128, cout=384, k=1, stride=1, pad=0, H=5, W=33, act=1, bias=True, resid=True, scale=True),
     dict(cin=192, cout=192, k=1, stride=1, pad=0, H=9, W=16, act=1, bias=True, resid=True, scale=True),
+    dict(cin=32, cout=128, k=3, stride=2, pad=1, H=16, W=70, act=1, bias=True, resid=False, scale=True),       # ... stride 2
     # LDS-staged kernel (conv_split3.inc): 3x3, stride 2, transposed, 1x1 fallbacks, channel tails
     dict(cin=8, cout=16, k=3, stride=1, pad=1, H=12, W=20, act=1, bias=True, resid=True, scale=True),
     dict(cin=12, cout=40, k=3, stride=1, pad=1, H=9, W=7, act=0, bias=False, resid=False, scale=False),
@@ -376,6 +380,7 @@ F16_MIXED = [
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=False, scale=True),         # persistent GEMM (conv1)
     dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=1, bias=True, resid=True, scale=True),         # ... with a residual: falls through
     dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),         # 1x1 wreg shape: falls through
+    dict(cin=64, cout=200, k=3, stride=2, pad=1, H=11, W=37, act=1, bias=True, resid=False, scale=True),        # weights-in-registers, stride 2 (last downsample)
     dict(cin=8, cout=16, k=3, stride=2, pad=1, H=16, W=24, act=1, bias=True, resid=False, scale=True),          # LDS-staged, the last downsample
     dict(cin=12, cout=40, k=3, stride=1, pad=1, H=9, W=7, act=0, bias=False, resid=True, scale=False),
     dict(cin=24, cout=70, k=3, stride=2, pad=1, H=9, W=34, act=1, bias=True, resid=False, scale=True, transposed=True),   # first upsample

@@ -47,10 +47,15 @@ def main():
     table = {
         'convA': lambda: conv(512, 128, 3, h, w),
         'convB': lambda: conv(128, 384, 3, h, w, x2c=192),
+        'convA128': lambda: conv(512, 128, 3, 128, 128),
+        'convB128': lambda: conv(128, 384, 3, 128, 128, x2c=192),
         'conv1': lambda: conv(384, 192, 1, h, w),
         'fuconv': lambda: conv(384, 384, 1, h, 33),
         'down1': lambda: conv(64, 128, 3, 512, 512, stride=2),
+        'down2': lambda: conv(128, 256, 3, 256, 256, stride=2),
         'down3': lambda: conv(256, 512, 3, 128, 128, stride=2),
+        'up1': lambda: conv(512, 256, 3, 64, 64, tr=True),
+        'up2': lambda: conv(256, 128, 3, 128, 128, tr=True),
         'up3': lambda: conv(128, 64, 3, 256, 256, tr=True),
         'stem': lambda: conv(4, 64, 7, 512, 512),
         'head': lambda: conv(64, 3, 7, 512, 512),
