@@ -34,6 +34,9 @@ The JSON line also carries
   value_with_h2d_d2h -- the same step fed from pinned host buffers (fp32 image + mask in, u8 out) over PCIe,
                    copies on the compute stream (not overlapped).  Never `value`.
 
+  configs2_fp16_leg / configs4_refine_leg -- the other single-GPU configs of BASELINE.json (4 x 1024^2 with fp16 activations beside the
+                   fp32-accurate default; refine_predict on one 2048^2 image), rank 0, N = 1 only.  Never `value`.
+
 `--gpus N` without a torch.distributed environment re-executes itself under torch.distributed.run with N
 ranks (one per GPU, RCCL) and relays rank 0's JSON line.
 """
@@ -216,6 +219,33 @@ def cpu_one_thread_leg():
         O.training_module_forward(dict(image=img.clone(), mask=mask.clone()), sd, cfg)
         dt = time.perf_counter() - t0
     print(json.dumps(dict(images_per_s=round(1.0 / dt, 4), images=1, threads=torch.get_num_threads(), seconds=round(dt, 1))), flush=True)
+
+
+def configs4_refine_leg(model, device, res=2048, n_iters=15):
+    """BASELINE configs[4]: refine_predict on one synthetic res x res image (refiner defaults of configs/prediction/default.yaml with
+    px_budget = 4194304 so that the full resolution is kept): seconds per image, second run (plans and packed reverse-pass weights
+    cached)."""
+    from lama_amd import refinement as R
+    g = torch.Generator().manual_seed(5)
+    img = torch.rand(1, 3, res, res, generator=g).to(device)
+    mask = torch.zeros(1, 1, res, res)
+    mask[:, :, res // 4: res // 2, res // 4: 3 * res // 4] = 1.0
+    mask = mask.to(device)
+    model.generator.use_graph = False
+    dts = []
+    for _ in range(2):
+        batch = dict(image=img, mask=mask, unpad_to_size=[torch.tensor([res]), torch.tensor([res])])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        R.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=n_iters, lr=0.002, min_side=512, max_scales=3, px_budget=4194304)
+        torch.cuda.synchronize()
+        dts.append(time.perf_counter() - t0)
+    for plan_owner in (model.generator,):
+        plan_owner._plans.clear()
+    torch.cuda.empty_cache()
+    return dict(value=round(dts[-1], 3), unit='s per image', first_run_s=round(dts[0], 3),
+                workload=f'big-lama refine_predict, 1 x {res}x{res}, n_iters={n_iters}, 3 scales (512 / 1024 / 2048), forward f16x3 + reverse pass bf16x3',
+                peak_memory_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
 
 
 def sustained_mfma_peak(device, seconds=0.25):
@@ -483,6 +513,16 @@ def main():
             c3_leg = dict(error=repr(e)[:300])
         model.generator.set_precision(precision)
 
+    # extra leg (rank 0, N = 1): BASELINE configs[4] -- refinement of one 2048x2048 image (px_budget 4194304, 15 iterations, 3 scales)
+    c5_leg = None
+    if rank == 0 and world == 1 and not args.no_f32_leg and BATCH == 8 and RES == 512:
+        try:
+            c5_leg = configs4_refine_leg(model, device)
+        except Exception as e:      # noqa: BLE001
+            c5_leg = dict(error=repr(e)[:300])
+        model.generator.set_precision(precision)
+        model.generator.use_graph = not args.no_graph
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model)
@@ -510,7 +550,7 @@ def main():
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'hip_graph': not args.no_graph, 'precision': args.precision},
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
-            'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg,
+            'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg,
             'value_with_h2d_d2h': None if dt_pcie is None else dict(
                 value=round(BATCH * args.steps / dt_pcie, 3), unit='images/s', ms_per_step=round(dt_pcie / args.steps * 1e3, 3),
                 note=f'pinned host fp32 image+mask in ({BATCH * 4 * RES * RES * 4 / 1e6:.1f} MB), u8 out ({BATCH * 3 * RES * RES / 1e6:.1f} MB) '
