@@ -41,14 +41,14 @@ def save_exported(model: trainers.DefaultInpaintingTrainingModule, save_path: st
                 config=dict(generator=dict(model.config['generator']),
                             training_model=dict(kind='default', concat_mask=bool(model.concat_mask))),
                 state_dict={'generator.' + k: v.detach().cpu() for k, v in gen.state_dict().items()},
-                shapes=[tuple(int(v) for v in s) for s in shapes])
+                shapes=[[int(v) for v in s] for s in shapes])
     os.makedirs(os.path.dirname(os.path.abspath(save_path)) or '.', exist_ok=True)
     torch.save(blob, save_path)
 
 
 def load_exported(path: str, device='cuda', executor=None) -> JITWrapper:
     """The exported file -> ``wrapper(image, mask) -> inpainted`` on ``device`` (hipGraph replay per input shape)."""
-    blob = torch.load(path, map_location='cpu', weights_only=False)
+    blob = torch.load(path, map_location='cpu', weights_only=True)      # tensors + plain containers only: nothing to unpickle
     if not isinstance(blob, dict) or blob.get('format') != FORMAT:
         raise L.LamaError(f'{path}: not a {FORMAT} file')
     model = trainers.make_training_model(blob['config'])

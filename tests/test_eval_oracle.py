@@ -122,3 +122,29 @@ def test_fid_lpips_need_the_downloaded_networks():
     ref = ((mu1 - mu2) ** 2).sum() + np.trace(s1) + np.trace(s2) - 2 * np.trace(linalg.sqrtm(s1.dot(s2)).real)
     assert abs(total['mean'] - ref) < 1e-6 * max(1.0, abs(ref)) and np.isnan(groups[2]['mean']) and np.isfinite(groups[0]['mean'])
     assert EV.ssim_fid100_f1({('ssim', 'total'): dict(mean=0.9), ('fid', 'total'): dict(mean=10.0)}) == pytest.approx(2 * 0.9 * 0.9 / (1.8 + 1e-3))
+
+
+def test_export_roundtrip_emulated(tmp_path):
+    """bin/to_jit.py analogue on the host emulator: checkpoint dir -> one file -> reloaded callable, the reference's self-check
+    (sum |output - exported output|) is 0, the file holds only tensors and plain containers (torch.load(weights_only=True))."""
+    import yaml
+    from oracle import lama_oracle as O
+    from lama_amd import export as X, ffc as F
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = O.make_synthetic_state_dict(cfg, seed=3, calib_hw=32)
+    os.makedirs(tmp_path / 'm' / 'models')
+    with open(tmp_path / 'm' / 'config.yaml', 'w') as f:
+        yaml.safe_dump(dict(training_model=dict(kind='default', concat_mask=True), generator=dict(kind='ffc_resnet', **cfg)), f)
+    torch.save({'state_dict': {'generator.' + k: v for k, v in sd.items()}}, tmp_path / 'm' / 'models' / 'best.ckpt')
+    ex = F._Exec(emu_lib())
+    res = X.export(str(tmp_path / 'm'), str(tmp_path / 'o' / 'x.pt'), size=40, executor=ex)
+    assert res == dict(diff=0.0, max=0.0)
+    w = X.load_exported(str(tmp_path / 'o' / 'x.pt'), executor=ex)
+    g = torch.Generator().manual_seed(2)
+    img, msk = torch.rand(1, 3, 32, 48, generator=g), (torch.rand(1, 1, 32, 48, generator=g) > 0.6).float()
+    out = w(img, msk)
+    with torch.no_grad():
+        pred = O.generator_forward(torch.cat([img * (1 - msk), msk], 1), sd, cfg)
+    assert float((out - (msk * pred + (1 - msk) * img)).abs().max()) < 2e-4
+    with pytest.raises(Exception):
+        X.load_exported(str(tmp_path / 'm' / 'models' / 'best.ckpt'), executor=ex)      # not an exported file
