@@ -152,7 +152,8 @@ def _inv_ref(spec, h, w):
 
 
 FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32), (128, 128),   # fused LDS path (64 / 128 squares: one-buffer kernels)
-             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13),          # generic DFT path
+             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13),          # generic DFT path (one Cooley-Tukey split; primes: direct)
+             (45, 60), (21, 94), (27, 25),                                    # ... 9x5 / 6x10, 3x7 / 2x47, 3x9 / 5x5
              (256, 32), (16, 512), (256, 256)]                                # two-pass LDS path
 
 
