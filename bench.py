@@ -204,7 +204,10 @@ def cpu_baseline(model, budget_s=10.0):
     return dict(value=round(n / t_used, 4), unit='images/s', cores=nthr, kind='port',
                 sample=f'{n} of the {BATCH} 512x512 images, batch-1 loop (bin/predict.py mode), oracle/lama_oracle.py '
                        f'(reference arithmetic on torch-CPU {torch.__version__}), {t_used:.1f} s, torch threads capped at {nthr} of '
-                       f'{ncpu} logical cores', modes=modes)
+                       f'{ncpu} logical cores', modes=modes,
+                reference_classes='the reference\'s own FFCResNetGenerator classes cannot travel to the GPU box; timed beside this restatement '
+                                  'in the build container (8 cores): bit-identical output, 0.91-1.11x its speed in all three modes '
+                                  '(profiles/r02_reference_cpu_timing.txt, tools/ref_cpu_timing.py)')
 
 
 def cpu_one_thread_leg():
