@@ -473,6 +473,14 @@ def main():
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
                              'algorithmic product; achieved counts algorithmic FLOPs only')
+            # the runner-up by total time (the two bottleneck 3x3 launches are within a few per cent of each other: which one is
+            # "dominant" flips from box to box)
+            others = sorted((k for k in kern if k.startswith('conv') and k != dom and timer.flops.get(k)), key=lambda k: -kern[k]['total_us'])
+            if others:
+                k2 = others[0]
+                a2 = timer.flops[k2] / kern[k2]['avg_us'] / 1e6
+                roof['runner_up'] = dict(kernel=k2, achieved=round(a2, 2), frac=round(a2 / peak, 4), avg_us=round(kern[k2]['avg_us'], 2),
+                                         launches_per_step=kern[k2]['n'] // 3)
             if precision != L.PREC_F32:
                 sus = sustained_mfma_peak(device)
                 if sus and sus.get('value'):
