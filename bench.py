@@ -393,15 +393,15 @@ def main():
     timer = KernelTimer(lib)
     model = build_model(device, precision)
     model.generator.use_graph = not args.no_graph
-    model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '0')))   # experimental, see lama_amd/ffc.py
+    model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # the generator's default; 0 = serial launch order (A/B runs)
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
     gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if world > 1 else None
 
-    def step():
+    def step(collect=True):
         out = model(dict(image=img, mask=mask))
         lib.quantize_u8_hwc(L.view(out['inpainted']), u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
-        if world > 1:
+        if world > 1 and collect:
             dist.all_gather_into_tensor(gathered, u8)       # the only data-path collective: output images
 
     def barrier():
@@ -452,14 +452,16 @@ def main():
         model.generator.use_graph = False
         model.generator.overlap_streams = False     # per-kernel events need every launch on the current stream
         model.generator._plans.clear()
-        step()
+        step(collect=False)                         # rank 0 only: no collective in here (the other ranks are done)
         torch.cuda.synchronize()
         timer.on = True
         for _ in range(3):
-            step()
+            step(collect=False)
         torch.cuda.synchronize()
         timer.on = False
         kern = timer.summary()
+        model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # back to the timed configuration
+        model.generator._plans.clear()
         dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])
         h = RES // 8
         flops = timer.flops.get(dom)
@@ -570,6 +572,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                  # rank 0 is still busy with its roofline section when the others get here
         dist.destroy_process_group()
 
 
