@@ -471,6 +471,10 @@ def main():
             roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
                         traffic=(pmc_traffic(dom, args.precision) or {}).get('traffic_bytes'), traffic_detail=pmc_traffic(dom, args.precision),
                         avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
+                        measured='HIP events around every launch in 3 eager steps in SERIAL launch order (each kernel alone on the GPU; '
+                                 'rocprofv3 of `LAMA_OVERLAP_STREAMS=0 python bench.py`: profiles/r02_kernel_stats.csv).  The timed region runs the '
+                                 'spectral branch on a second stream: the same kernels then take 8-12 % longer each (shared CUs) and the step 3 % less '
+                                 '(profiles/r02_kernel_stats_overlap_on_slow_box.csv, r02_ab_bench_overlap_streams.txt)',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
