@@ -242,6 +242,59 @@ def test_fourier_unit_c2_shape(lib, prec):
     assert float((y.cpu() - ref).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize('shape', [(8, 192, 64, 64), (4, 192, 128, 128), (1, 192, 256, 256), (1, 48, 135, 240)],
+                         ids=['c2_64', 'c3_128', 'c5_256', 'photo_135x240'])
+def test_fft_round_trip_and_parseval_full_size(lib, shape):
+    """Size-independent properties at the BASELINE plane sizes (no CPU reference needed): irfft2(rfft2(x)) = x, the fused residual
+    doubles it (x + irfft2(rfft2(x)) = 2x), and the ortho transform keeps the energy (Parseval on the half spectrum with the
+    interior kx bins counted twice)."""
+    B, Cn, h, w = shape
+    g = torch.Generator().manual_seed(h + w)
+    x = torch.randn(B, Cn, h, w, generator=g).to(DEV)
+    wf = w // 2 + 1
+    spec = torch.zeros(B, 2 * Cn, h, wf, device=DEV)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rfft2(L.view(x), L.view(spec), B, ws, stream=st)
+    y = torch.zeros_like(x)
+    lib.irfft2(L.view(spec), None, L.view(y), B, ws, stream=st)
+    y2 = torch.zeros_like(x)
+    lib.irfft2(L.view(spec), L.view(x), L.view(y2), B, ws, stream=st)
+    torch.cuda.synchronize()
+    tol = 2e-5 if max(h, w) <= 128 else 1e-4
+    assert float((y - x).abs().max()) < tol and float((y2 - 2 * x).abs().max()) < 2 * tol
+    sp = spec.view(B, Cn, 2, h, wf).double()
+    wgt = torch.full((wf,), 2.0, dtype=torch.float64, device=DEV)
+    wgt[0] = 1.0
+    if w % 2 == 0:
+        wgt[-1] = 1.0
+    e_spec = ((sp ** 2).sum(2) * wgt).sum(dim=(-2, -1))
+    e_x = (x.double() ** 2).sum(dim=(-2, -1))
+    assert float(((e_spec - e_x).abs() / e_x).max()) < 1e-5
+
+
+@pytest.mark.parametrize('prec', [L.PREC_F16X3, L.PREC_BF16X3], ids=['f16x3', 'bf16x3'])
+def test_conv_linearity_full_size(lib, prec):
+    """conv(a x + b y) = a conv(x) + b conv(y) for the local 3x3 launch at the BASELINE configs[1] shape [8,512,64,64] -> 128 channels
+    (no bias / activation): a property of the launch that needs no CPU reference at this size."""
+    g = torch.Generator().manual_seed(17)
+    B, cin, cout, H, W = 8, 512, 128, 64, 64
+    x, y = torch.randn(B, cin, H, W, generator=g).to(DEV), torch.randn(B, cin, H, W, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) * 0.02).to(DEV)
+    wp = lib.pack_conv_weight(wt, None, precision=prec)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def conv(t):
+        o = torch.zeros(B, cout, H, W, device=DEV)
+        lib.conv2d(L.view(t), wp, L.view(o), B, 3, 1, 1, L.PAD_REFLECT, False, None, L.ACT_NONE, None, precision=prec, stream=st)
+        return o
+    a, b = 0.75, -1.5
+    lhs, rhs = conv(a * x + b * y), a * conv(x) + b * conv(y)
+    torch.cuda.synchronize()
+    scale = float(rhs.abs().max())
+    assert float((lhs - rhs).abs().max()) < (2e-5 if prec == L.PREC_F16X3 else 2e-4) * max(1.0, scale)
+
+
 def test_elementwise(lib):
     g = torch.Generator().manual_seed(9)
     B, H, W = 2, 40, 56
