@@ -143,6 +143,36 @@ def test_biglama_512_batch8_all_images(big):
         gen.use_graph = False
 
 
+def test_training_module_properties_at_configs1_size():
+    """DefaultInpaintingTrainingModule.forward at 8x512x512 (BASELINE configs[1]) through properties that need no CPU pass: outside the
+    hole the inpainted image IS the input (bitwise: inpainted = m pred + (1 - m) img, trainers/default.py:71), inside it is the
+    prediction; the generator never sees the pixels under the hole (changing them changes nothing); the u8 HWC result is the
+    clipped x255 truncation of the float result (bin/predict.py:86-92)."""
+    from lama_amd import trainers
+    cfg = O.BIG_LAMA
+    if 'sd' not in _BIG_SD:
+        _BIG_SD['sd'] = O.make_synthetic_state_dict(cfg, seed=0, calib_hw=64)
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
+    model.generator.load_state_dict(_BIG_SD['sd'], strict=True)
+    model.freeze()
+    model.cuda()
+    batch = O.make_synthetic_batch(8, 512, 512, seed=4242)
+    img, mask = batch['image'].cuda(), batch['mask'].cuda()
+    out = model(dict(image=img, mask=mask))
+    inp, pred = out['inpainted'], out['predicted_image']
+    keep = (mask == 0).expand_as(img)
+    assert torch.equal(inp[keep], img[keep]) and torch.equal(inp[~keep], pred[~keep])
+    img2 = torch.where(keep, img, torch.rand_like(img))                  # other pixels under the hole
+    out2 = model(dict(image=img2, mask=mask))
+    assert torch.equal(out2['predicted_image'], pred)
+    u8 = torch.empty(8, 512, 512, 3, dtype=torch.uint8, device='cuda')
+    lib = model.generator._exec.lib
+    lib.quantize_u8_hwc(L.view(inp), u8, 8, 512, 512, torch.cuda.current_stream().cuda_stream)
+    ref_u8 = torch.clamp(inp.permute(0, 2, 3, 1) * 255, 0, 255).to(torch.uint8)
+    assert torch.equal(u8, ref_u8)
+    model.generator._plans.clear()
+
+
 @pytest.mark.parametrize('res', [1024, 2048], ids=['1024sq_planes128', '2048sq_planes256'])
 def test_biglama_high_res_square(big, res):
     """BASELINE configs[2] / configs[4] resolutions at batch 1 against the full oracle: 1024^2 -> 128 x 128 bottleneck planes
