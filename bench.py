@@ -130,8 +130,14 @@ class KernelTimer:
         key = f'conv{k}x{k}{"T" if tr else ""}_cin{x.C}_cout{y.C}_{y.H}x{y.W}' + (f'+1x1_cin{x2.C}' if x2 is not None else '')
         # algorithmic FLOPs of the launch (2*M*N*K; a transposed conv touches 9/4 taps per output pixel)
         kterm = x.C * k * k / (4.0 if tr else 1.0) + (x2.C if x2 is not None else 0)
-        self.flops[key] = 2.0 * batch * y.H * y.W * y.C * kterm
-        self.bytes[key] = 4.0 * batch * (x.C * x.H * x.W + y.C * y.H * y.W + (x2.C * x2.H * x2.W if x2 is not None else 0))
+        flops = 2.0 * batch * y.H * y.W * y.C * kterm
+        nbytes = 4.0 * batch * (x.C * x.H * x.W + y.C * y.H * y.W + (x2.C * x2.H * x2.W if x2 is not None else 0))
+        f1 = kw.get('fuse1')
+        if f1 is not None:      # SpectralTransform.conv1 of the next layer rides in this launch's epilogue: its flops and its output count here
+            key += f'+next_conv1x1_cout{f1[2].C}'
+            flops += 2.0 * batch * y.H * y.W * f1[2].C * y.C
+            nbytes += 4.0 * batch * f1[2].C * y.H * y.W
+        self.flops[key], self.bytes[key] = flops, nbytes
         return self._timed(key, self._conv, x, w_packed, y, batch, k, *a, **kw)
 
     def fourier_unit(self, x, *a, **kw):
@@ -154,8 +160,10 @@ def pmc_traffic(kernel_key, precision):
             d = json.load(open(f))
         except Exception:
             continue
-        e = d.get(precision, {}).get(kernel_key)
+        e = d.get(precision, {}).get(kernel_key) or d.get(precision, {}).get(kernel_key.split('+next_')[0])
         if e:
+            if '+next_' in kernel_key:
+                e = dict(e, note_fused='counters of the launch WITHOUT the fused conv1 of the next layer (+25 MB of x1 written)')
             return dict(e, source=os.path.relpath(f, ROOT))
     return None
 
@@ -394,6 +402,7 @@ def main():
     model = build_model(device, precision)
     model.generator.use_graph = not args.no_graph
     model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # the generator's default; 0 = serial launch order (A/B runs)
+    model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '1')))         # the generator's default; 0 for A/B runs
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
     gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if world > 1 else None

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 103
+#define LAMA_HIP_VERSION 104
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -91,7 +91,20 @@ typedef struct lama_conv2d_args {
      * uint32, zeroed by the caller); its output is then garbage and the caller re-runs with LAMA_PREC_BF16X3 (fp32 exponent
      * range, 16 mantissa bits) or LAMA_PREC_F32.  The weights are range-checked by the host at pack time instead. */
     uint32_t* range_flag;
+    /* Optional fused second stage (NULL / ptr NULL = off): SpectralTransform.conv1 of the NEXT layer, ffc.py:128-133,145, i.e.
+     *     fuse1_y = ReLU( W1 y + fuse1_bias ),  W1 [192, 384] 1x1,
+     * computed in the epilogue of the launch that produces the 384-channel x_g state y (the global branch of an FFC layer:
+     * 3x3 over x_l + fused 1x1 over x2, Cout = 384, fp32 tensors, LAMA_PREC_F16X3 / BF16X3, planes of at least one 128-pixel
+     * tile per CU; anything else returns LAMA_ERR_UNSUPPORTED when fuse1_w is set -- the caller then launches conv1 itself).
+     * fuse1_w = lama_conv2d_pack_weight of W1 (BatchNorm scale folded) whose INPUT channels were reordered with
+     * lama_fuse1_channel_order (the accumulator layout of the producing kernel); fuse1_y [B,192,H,W] fp32. */
+    const void* fuse1_w;
+    const float* fuse1_bias;
+    lama_tensor fuse1_y;
 } lama_conv2d_args;
+
+/* order[k] = the input channel of conv1 that sits at packed K position k (0 <= k < 384) of lama_conv2d_args.fuse1_w */
+void lama_fuse1_channel_order(int32_t* order);
 
 int lama_version(void);
 const char* lama_error_string(int code);

@@ -469,6 +469,15 @@ extern "C" int lama_conv2d_pack_weight(void* stream, const float* w, const float
     return LAMA_OK;
 }
 
+// packed K position k = 16 kq + 8 khalf + i of lama_conv2d_args.fuse1_w holds input channel 32 F + 16 ks + 8 (i / 4) + 4 khalf + i % 4 with
+// kq = 2 F + ks: the row (r & 3) + 8 (r >> 2) + 4 khalf that accumulator register r = 8 ks + i of lane half khalf holds in the
+// 32-row fragment F of the producing kernel (conv_wreg_dev.inc)
+extern "C" void lama_fuse1_channel_order(int32_t* order) {
+    for (int kq = 0; kq < 24; ++kq)
+        for (int kh = 0; kh < 2; ++kh)
+            for (int i = 0; i < 8; ++i) order[16 * kq + 8 * kh + i] = 32 * (kq / 2) + 16 * (kq & 1) + 8 * (i / 4) + 4 * kh + (i % 4);
+}
+
 extern "C" int lama_conv2d_fwd(void* stream, const lama_conv2d_args* a) {
     if (!a || !tensor_ok(a->x) || !tensor_ok(a->y) || !a->w_packed || a->batch <= 0) return LAMA_ERR_BAD_ARG;
     if (a->precision != LAMA_PREC_F32 && a->precision != LAMA_PREC_BF16X3 && a->precision != LAMA_PREC_F16X3 && a->precision != LAMA_PREC_F16)
@@ -497,6 +506,12 @@ extern "C" int lama_conv2d_fwd(void* stream, const lama_conv2d_args* a) {
     const bool has2 = a->x2.ptr != nullptr;
     if (has2 && (a->transposed || !a->w2_packed || a->x2.H != Ho || a->x2.W != Wo || !tensor_ok(a->x2))) return LAMA_ERR_BAD_ARG;
     if (a->resid.ptr && (a->resid.C != cout || a->resid.H != Ho || a->resid.W != Wo)) return LAMA_ERR_BAD_ARG;
+    if (a->fuse1_w) {   // fused conv1 of the next layer: only the launch that produces the 384-channel state, on the split precisions
+        if (!tensor_ok(a->fuse1_y) || a->fuse1_y.dtype != LAMA_DT_F32 || a->fuse1_y.C != 192 || a->fuse1_y.H != Ho || a->fuse1_y.W != Wo) return LAMA_ERR_BAD_ARG;
+        if (cout != 384 || !has2 || a->kh != 3 || a->stride != 1 || a->y.dtype != LAMA_DT_F32 ||
+            (a->precision != LAMA_PREC_BF16X3 && a->precision != LAMA_PREC_F16X3))
+            return LAMA_ERR_UNSUPPORTED;
+    }
     if (a->precision == LAMA_PREC_BF16X3) return lama_cb_conv2d_fwd_bf16x3((hipStream_t)stream, a, Ho, Wo);
     if (a->precision == LAMA_PREC_F16X3) return lama_cb_conv2d_fwd_f16x3((hipStream_t)stream, a, Ho, Wo);
     if (a->precision == LAMA_PREC_F16) return lama_cb_conv2d_fwd_f16((hipStream_t)stream, a, Ho, Wo);

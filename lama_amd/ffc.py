@@ -105,6 +105,7 @@ class _Exec:
         self.injected = lib is not None
         self._flags = {}
         self._depth = 0
+        self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
 
     @property
@@ -276,11 +277,30 @@ class SpectralTransform(_HipModule):
                                 w2=lib.pack_conv_weight(self.conv2.weight.detach(), out_scale, precision=self.precision))
         return self._packed
 
-    def run_front(self, xg: L.Tensor4, x1: torch.Tensor, t: torch.Tensor, ws: torch.Tensor, batch: int, stream: int):
-        """x1 = relu(bn(conv1(xg))); t = x1 + fu(x1).  (conv2 is fused by the caller.)"""
+    def run_front(self, xg: L.Tensor4, x1: torch.Tensor, t: torch.Tensor, ws: torch.Tensor, batch: int, stream: int,
+                  x1_ready: bool = False):
+        """x1 = relu(bn(conv1(xg))); t = x1 + fu(x1).  (conv2 is fused by the caller.)  ``x1_ready``: the producer of xg already
+        wrote x1 from its epilogue (fuse1_operands)."""
         pk = self._packed
-        self._exec.conv2d(xg, pk['w1'], L.view(x1), batch, 1, bias=pk['b1'], act=L.ACT_RELU, precision=self.precision, stream=stream)
+        if not x1_ready:
+            self._exec.conv2d(xg, pk['w1'], L.view(x1), batch, 1, bias=pk['b1'], act=L.ACT_RELU, precision=self.precision, stream=stream)
         self.fu.run(L.view(x1), L.view(t), batch, True, ws, stream)
+
+    def fuse1_operands(self, x1: torch.Tensor) -> Optional[tuple]:
+        """(packed conv1 weights in the channel order of the producing kernel's accumulators, BatchNorm shift, x1 view) for the
+        ``fuse1`` argument of the launch that PRODUCES this layer's x_g -- or None when conv1 cannot ride there (shape / precision)."""
+        conv = self.conv1[0]
+        if self.precision not in (L.PREC_F16X3, L.PREC_BF16X3) or conv.in_channels != 384 or conv.out_channels != 192 or x1.dtype != torch.float32:
+            return None
+        pk = self._packed
+        if pk is None:
+            return None
+        if 'w1f' not in pk:
+            lib = self._exec.lib
+            s1, _ = _bn_fold(self.conv1[1])
+            order = lib.fuse1_channel_order().to(conv.weight.device)
+            pk['w1f'] = lib.pack_conv_weight(conv.weight.detach()[:, order].contiguous(), s1, precision=self.precision)
+        return pk['w1f'], pk['b1'], L.view(x1)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._exec.check(x)
@@ -380,13 +400,18 @@ class FFC(_HipModule):
 
     # -- launch --------------------------------------------------------------------------------------
     def launch(self, pk: dict, act: int, src: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict],
-               resid: Optional[torch.Tensor] = None, extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None):
+               resid: Optional[torch.Tensor] = None, extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None,
+               x1_ready: bool = False, fuse_next: Optional['SpectralTransform'] = None) -> bool:
         """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous), as 1 launch (no global
         input) or 6 launches (conv1x1, rfft2, spectral conv1x1, irfft2+add, fused local conv, fused global conv).
 
         ``side``: optional second HIP stream.  The spectral branch (conv1 -> rfft2 -> spectral 1x1 -> irfft2, HBM/latency
         bound, small LDS footprint) then runs on it concurrently with the MFMA-bound local 3x3 conv of the main stream; the
-        two join before the global conv that consumes both.  Works inside hipGraph capture (fork/join via events)."""
+        two join before the global conv that consumes both.  Works inside hipGraph capture (fork/join via events).
+
+        ``x1_ready``: scratch['x1'] already holds conv1 of this layer (written by the previous layer's global launch).
+        ``fuse_next``: the SpectralTransform of the NEXT layer: its conv1 rides in the epilogue of this layer's global launch
+        (lama_conv2d_args.fuse1_*).  Returns True when it did (the next layer then passes x1_ready=True)."""
         f, ex, prec = self, self._exec, self.precision
         B = src.shape[0]
         st = ex.stream(src)
@@ -394,23 +419,42 @@ class FFC(_HipModule):
         if f.in_cg == 0:
             ex.conv2d(L.view(src), pk['w_all'], L.view(dst), B, f.kernel_size, f.stride, pad, L.PAD_REFLECT, False, pk['b_all'],
                       act, None if resid is None else L.view(resid), precision=prec, stream=st)
-            return
+            return False
         cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
         spec = f.convg2g
         if side is not None and src.is_cuda:
             main = torch.cuda.current_stream(src.device)
             side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
-            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream)
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
             ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
             main.wait_stream(side)                      # join: t is ready for the global conv
         else:
-            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st)
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
             ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
-        ex.conv2d(L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], act,
-                  None if resid is None else L.view(resid, ocl, ocg), x2=L.view(scratch['t']), w2_packed=spec._packed['w2'],
-                  precision=prec, stream=st)
+        # the global branch; by the time it runs this layer's own x1 has been consumed (rfft2 and the x + fu(x) add are upstream of t)
+        fuse1 = None
+        shape_key = (tuple(src.shape), prec)
+        # only when the global launch fills the chip (one 128-pixel tile per CU and more): on a few dozen tiles the epilogue GEMM runs on
+        # a few dozen CUs while a launch of its own would use all of them (4 x 256^2: 587 -> 648 images/s with conv1 on its own)
+        tiles = B * ((dst.shape[2] * dst.shape[3] + 127) // 128)
+        if (fuse_next is not None and f.kernel_size == 3 and f.stride == 1 and ocg == 384 and shape_key not in ex.no_fuse1
+                and (tiles >= 192 or ex.injected)):
+            fuse1 = fuse_next.fuse1_operands(scratch['x1'])
+        gargs = (L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], act,
+                 None if resid is None else L.view(resid, ocl, ocg))
+        gkw = dict(x2=L.view(scratch['t']), w2_packed=spec._packed['w2'], precision=prec, stream=st)
+        if fuse1 is not None:
+            try:
+                ex.conv2d(*gargs, fuse1=fuse1, **gkw)
+                return True
+            except LamaError as e:
+                if 'unsupported' not in str(e):
+                    raise
+                ex.no_fuse1.add(shape_key)    # e.g. planes too small for the 12 x 1 launch: at this shape conv1 stays a launch of its own
+        ex.conv2d(*gargs, **gkw)
+        return False
 
     def out_shape(self, src_shape, extra_pad: int = 0):
         B, _, H, W = src_shape
@@ -476,11 +520,16 @@ class FFC_BN_ACT(_HipModule):
 
     # -- launch --------------------------------------------------------------------------------------
     def run(self, src: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], resid: Optional[torch.Tensor] = None,
-            extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None):
+            extra_pad: int = 0, side: Optional['torch.cuda.Stream'] = None, x1_ready: bool = False,
+            fuse_next: Optional['FFC_BN_ACT'] = None) -> bool:
         f = self.ffc
         if f.in_cg and self._packed is not None and (f.convg2g._packed or {}).get('fused_scale') != id(self._packed.get('_sg')):
             self._packed = None   # a stand-alone SpectralTransform.forward / FFC.forward re-packed conv2 without bn_g
-        f.launch(self._pack(), self._act, src, dst, scratch, resid, extra_pad, side)
+        nxt = None
+        if fuse_next is not None and fuse_next.ffc.in_cg:
+            fuse_next._pack()                                  # its conv1 weights must exist before they can ride along
+            nxt = fuse_next.ffc.convg2g
+        return f.launch(self._pack(), self._act, src, dst, scratch, resid, extra_pad, side, x1_ready, nxt)
 
     def out_shape(self, src_shape, extra_pad: int = 0):
         return self.ffc.out_shape(src_shape, extra_pad)
@@ -517,9 +566,13 @@ class FFCResnetBlock(_HipModule):
                                 activation_layer=activation_layer, padding_type=padding_type, **conv_kwargs)
         self.inline = inline
 
-    def run(self, src: torch.Tensor, tmp: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], side=None):
-        self.conv1.run(src, tmp, scratch, side=side)
-        self.conv2.run(tmp, dst, scratch, resid=src, side=side)
+    def run(self, src: torch.Tensor, tmp: torch.Tensor, dst: torch.Tensor, scratch: Optional[dict], side=None, x1_ready: bool = False,
+            next_block: Optional['FFCResnetBlock'] = None, fuse: bool = False) -> bool:
+        """``x1_ready`` / return value: conv1 of a layer's SpectralTransform may have been computed by the launch that produced the
+        layer's input (FFC.launch); ``next_block``: the block whose first conv1 this block's last launch computes."""
+        mid_ready = self.conv1.run(src, tmp, scratch, side=side, x1_ready=x1_ready, fuse_next=self.conv2 if fuse else None)
+        return self.conv2.run(tmp, dst, scratch, resid=src, side=side, x1_ready=mid_ready,
+                              fuse_next=None if next_block is None else next_block.conv1)
 
     def forward(self, x):
         x_l, x_g = x if type(x) is tuple else (x, 0)
@@ -749,6 +802,9 @@ class FFCResNetGenerator(_HipModule):
         # DESIGN.md 4.3): packed-fp32 VALU instructions with an op_sel swizzle are corrupted by another kernel's MFMA on the same
         # SIMD; the library is now built without them (lama_amd/build.py) and 100 000 overlapped layer runs are bit-identical.
         self.overlap_streams = True
+        # SpectralTransform.conv1 of every layer but the first rides in the epilogue of the launch that produces its input (the
+        # global branch of the previous layer): 35 of 36 pointwise launches less per forward
+        self.fuse_conv1 = True
         # fp16-split range watch (lama_conv2d_args.range_flag): one 4-byte read-back per forward; when an activation beyond 65504
         # (or a NaN) was met the forward is repeated with the 3-term bf16 split (fp32 exponent range) and the generator stays
         # on it.  auto_fallback = False raises LamaRangeError instead.
@@ -837,14 +893,19 @@ class FFCResNetGenerator(_HipModule):
         def B(name):
             return x if name == 'in' else bufs[name]
 
-        for st in plan['steps']:
+        steps = plan['steps']
+        x1_ready = False
+        for i, st in enumerate(steps):
             kind = st[0]
             if kind == 'ffc':
                 _, lay, s, d, pad = st
                 lay.run(B(s), B(d), plan['scratch'] if lay.ffc.in_cg else None, None, pad, side=plan['side'])
+                x1_ready = False
             elif kind == 'res':
                 _, lay, s, t, d = st
-                lay.run(B(s), B(t), B(d), plan['scratch'], side=plan['side'])
+                nxt = steps[i + 1][1] if self.fuse_conv1 and i + 1 < len(steps) and steps[i + 1][0] == 'res' else None
+                x1_ready = lay.run(B(s), B(t), B(d), plan['scratch'], side=plan['side'], x1_ready=x1_ready, next_block=nxt,
+                                   fuse=self.fuse_conv1)
             elif kind == 'up':
                 _, lay, s, d, bn, act = st
                 lay.run(B(s), B(d), bn, act)

@@ -201,3 +201,52 @@ def test_generator_fp16_activation_path(small):
         assert float((y2 - y).abs().max()) < 1e-6
     finally:
         gen.set_precision(L.PREC_F16X3)
+
+
+def test_conv1_rides_in_the_global_branch_epilogue():
+    """SpectralTransform.conv1 of every FFC layer but the first is computed in the epilogue of the launch that produces its input
+    (lama_conv2d_args.fuse1_*, big-lama channel counts only): same result as the stand-alone launches, one pointwise launch per
+    forward instead of one per layer, and the stand-alone path is taken again where the fused launch is refused."""
+    from lama_amd import _lib as L
+    cfg = O.small_config(ngf=64, n_blocks=2)                 # 512 channels at the bottleneck: (128 | 384) like big-lama
+    sd = O.make_synthetic_state_dict(cfg, seed=5, calib_hw=32)
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    ex = F._Exec(emu_lib())
+    gen.set_exec(ex)
+    batch = O.make_synthetic_batch(1, 32, 40, seed=2)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        ref = O.generator_forward(x, sd, cfg)
+    calls = dict(fused=0, conv1=0)
+    real = ex.lib.conv2d
+
+    def counting(xv, wp, yv, b, k, *a, **kw):
+        if kw.get('fuse1') is not None:
+            calls['fused'] += 1
+        if k == 1 and yv.C == 192 and xv.C == 384:
+            calls['conv1'] += 1
+        return real(xv, wp, yv, b, k, *a, **kw)
+    ex.lib.conv2d = counting
+    try:
+        for prec, tol in ((L.PREC_F16X3, 2e-4), (L.PREC_BF16X3, 5e-4)):
+            gen.set_precision(prec)
+            gen.fuse_conv1 = True
+            calls.update(fused=0, conv1=0)
+            y = gen(x)
+            assert calls == dict(fused=3, conv1=1), calls          # 4 FFC layers: the first conv1 alone, three in epilogues
+            gen.fuse_conv1 = False
+            gen._plans.clear()
+            calls.update(fused=0, conv1=0)
+            y0 = gen(x)
+            assert calls == dict(fused=0, conv1=4), calls
+            assert float((y - y0).abs().max()) < 2e-5 and float((y - ref).abs().max()) < tol, (float((y - y0).abs().max()), float((y - ref).abs().max()))
+            gen._plans.clear()
+        gen.set_precision(L.PREC_F32)                               # exact-fp32 path: never fused
+        gen.fuse_conv1 = True
+        calls.update(fused=0, conv1=0)
+        y32 = gen(x)
+        assert calls == dict(fused=0, conv1=4) and float((y32 - ref).abs().max()) < 1e-4
+    finally:
+        ex.lib.conv2d = real
+        gen.set_precision(L.PREC_F16X3)

@@ -295,6 +295,44 @@ def test_conv_linearity_full_size(lib, prec):
     assert float((lhs - rhs).abs().max()) < (2e-5 if prec == L.PREC_F16X3 else 2e-4) * max(1.0, scale)
 
 
+@pytest.mark.parametrize('prec', [L.PREC_F16X3, L.PREC_BF16X3], ids=['f16x3', 'bf16x3'])
+@pytest.mark.parametrize('hw', [(64, 64), (9, 37)], ids=['c2_64x64', 'ragged_9x37'])
+def test_conv2d_fused_next_conv1(lib, prec, hw):
+    """lama_conv2d_args.fuse1_*: SpectralTransform.conv1 of the next layer in the epilogue of the global-branch launch (3x3 over x_l +
+    1x1 over t + bias + ReLU + residual -> 384 channels).  y is bit-identical to the plain launch; x1 equals conv1 run on y as a launch
+    of its own (same products, another summation order) and the fp64 reference."""
+    g = torch.Generator().manual_seed(23)
+    B, cl, cg, half, (H, W) = (8 if hw[0] == 64 else 2), 128, 384, 192, hw
+    xl, t = torch.randn(B, cl, H, W, generator=g), torch.randn(B, half, H, W, generator=g)
+    w1, w2 = torch.randn(cg, cl, 3, 3, generator=g) * 0.03, torch.randn(cg, half, 1, 1, generator=g) * 0.05
+    scale, bias = torch.rand(cg, generator=g) + 0.5, torch.randn(cg, generator=g)
+    resid = torch.randn(B, cg, H, W, generator=g)
+    wc1 = torch.randn(192, cg, 1, 1, generator=g) * 0.05
+    s1, b1 = torch.rand(192, generator=g) + 0.5, torch.randn(192, generator=g) * 0.2
+    st = torch.cuda.current_stream().cuda_stream
+    d = lambda v: v.to(DEV)
+    wp1, wp2 = lib.pack_conv_weight(d(w1), d(scale), precision=prec), lib.pack_conv_weight(d(w2), d(scale), precision=prec)
+    order = lib.fuse1_channel_order()
+    assert sorted(order.tolist()) == list(range(384))
+    wpc_f = lib.pack_conv_weight(d(wc1[:, order].contiguous()), d(s1), precision=prec)
+    wpc = lib.pack_conv_weight(d(wc1), d(s1), precision=prec)
+    xld, td, rd, bd, b1d = d(xl), d(t), d(resid), d(bias), d(b1)
+    y0 = torch.zeros(B, cg, H, W, device=DEV); y = torch.zeros_like(y0)
+    x1 = torch.zeros(B, 192, H, W, device=DEV); x1s = torch.zeros_like(x1)
+    common = dict(x2=L.view(td), w2_packed=wp2, precision=prec, stream=st)
+    lib.conv2d(L.view(xld), wp1, L.view(y0), B, 3, 1, 1, L.PAD_REFLECT, False, bd, L.ACT_RELU, L.view(rd), **common)
+    lib.conv2d(L.view(y0), wpc, L.view(x1s), B, 1, bias=b1d, act=L.ACT_RELU, precision=prec, stream=st)
+    lib.conv2d(L.view(xld), wp1, L.view(y), B, 3, 1, 1, L.PAD_REFLECT, False, bd, L.ACT_RELU, L.view(rd), fuse1=(wpc_f, b1d, L.view(x1)), **common)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y0)
+    ref = torch.relu(torch.nn.functional.conv2d(y0.double().cpu(), (wc1 * s1[:, None, None, None]).double()) + b1.double()[None, :, None, None]).float()
+    tol = (2e-5 if prec == L.PREC_F16X3 else 2e-4) * max(1.0, float(ref.abs().max()))
+    assert float((x1.cpu() - ref).abs().max()) < tol and float((x1 - x1s).abs().max()) < tol
+    with pytest.raises(L.LamaError):      # the fused stage exists for the 384-channel global-branch launch only
+        lib.conv2d(L.view(xld), wp1, L.view(y), B, 3, 1, 1, L.PAD_REFLECT, False, bd, L.ACT_RELU, L.view(rd), fuse1=(wpc_f, b1d, L.view(x1)),
+                   precision=prec, stream=st)
+
+
 def test_elementwise(lib):
     g = torch.Generator().manual_seed(9)
     B, H, W = 2, 40, 56
