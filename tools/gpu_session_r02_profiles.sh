@@ -12,7 +12,7 @@ find $OUT/prof -name '*stats*.csv' | head -3
 for f in $(find $OUT/prof -name '*kernel_stats.csv' | head -1); do cp $f $OUT/rocprofv3_kernel_stats_raw.csv; done
 head -16 $OUT/kernel_stats.csv | cut -c1-160
 rm -rf $OUT/prof
-bash tools/pmc_session.sh $TAG/pmc_all "f16x3 convA convB rfft irfft down1 down2 down3 up1 up2 up3 stem head" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" > $OUT/pmc_all.log 2>&1
+bash tools/pmc_session.sh $TAG/pmc_all "f16x3 convA convB convBf rfft irfft down1 down2 down3 up1 up2 up3 stem head" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" > $OUT/pmc_all.log 2>&1
 bash tools/pmc_session.sh $TAG/pmc_conv1 "f16x3 conv1" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" > $OUT/pmc_conv1.log 2>&1
 bash tools/pmc_session.sh $TAG/pmc_fuconv "f16x3 fuconv" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" > $OUT/pmc_fuconv.log 2>&1
 tail -30 $OUT/pmc_all.log | cut -c1-200

@@ -26,7 +26,7 @@ def main():
     def rnd(*s):
         return torch.zeros(*s, device=dev) if zero else torch.randn(*s, generator=g).to(dev)
 
-    def conv(cin, cout, k, H, W, stride=1, tr=False, x2c=0):
+    def conv(cin, cout, k, H, W, stride=1, tr=False, x2c=0, fuse1=False):
         x = rnd(B, cin, H, W)
         wt = rnd(cin, cout, k, k) if tr else rnd(cout, cin, k, k)
         s2 = 2 if tr else stride
@@ -38,8 +38,16 @@ def main():
         if x2c:
             x2 = rnd(B, x2c, Ho, Wo)
             w2p = lib.pack_conv_weight(rnd(cout, x2c, 1, 1), None, precision=prec)
+        f1 = None
+        if fuse1:   # conv1 of the next layer in this launch's epilogue (lama_conv2d_args.fuse1_*)
+            order = lib.fuse1_channel_order()
+            w1f = lib.pack_conv_weight(rnd(192, cout, 1, 1)[:, order.to(dev)].contiguous(), None, precision=prec)
+            x1buf = torch.empty(B, 192, Ho, Wo, device=dev)
+            f1 = (w1f, rnd(192), L.view(x1buf), x1buf)          # the last entry keeps the buffer alive
+        resid = rnd(B, cout, Ho, Wo) if fuse1 else None
         return lambda: lib.conv2d(L.view(x), wp, L.view(y), B, k, s2, 1 if tr else k // 2, L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
-                                  L.ACT_RELU, None, None if x2 is None else L.view(x2), w2p, precision=prec, stream=st)
+                                  L.ACT_RELU, None if resid is None else L.view(resid), None if x2 is None else L.view(x2), w2p, precision=prec,
+                                  stream=st, fuse1=None if f1 is None else f1[:3])
 
     x1 = rnd(B, 192, h, w)
     spec = torch.empty(B, 384, h, w // 2 + 1, device=dev)
@@ -47,6 +55,7 @@ def main():
     table = {
         'convA': lambda: conv(512, 128, 3, h, w),
         'convB': lambda: conv(128, 384, 3, h, w, x2c=192),
+        'convBf': lambda: conv(128, 384, 3, h, w, x2c=192, fuse1=True),
         'convA128': lambda: conv(512, 128, 3, 128, 128),
         'convB128': lambda: conv(128, 384, 3, 128, 128, x2c=192),
         'conv1': lambda: conv(384, 192, 1, h, w),

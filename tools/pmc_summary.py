@@ -7,14 +7,14 @@ import sys
 
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
-    k = r.get('Kernel_Name', '')[:70]
+    k = r.get('Kernel_Name', '')[:130]
     g = r.get('Grid_Size') or r.get('Grid_Size_X') or ''
     if g:
-        k = f'{k[:58]} g={g}'
+        k = f'{k[:118]} g={g}'
     c = r.get('Counter_Name')
     v = float(r.get('Counter_Value', 0))
     a = acc[(k, c)]
     a[0] += v
     a[1] += 1
 for (k, c), (s, n) in sorted(acc.items()):
-    print(f'{k:70s} {c:28s} avg={s / n:16.1f} n={n}')
+    print(f'{k:130s} {c:28s} avg={s / n:16.1f} n={n}')
