@@ -130,7 +130,9 @@ def test_biglama_512_batch8_all_images(big):
     xd = x.cuda()
     y = gen(xd)
     y1 = gen(xd[3:4].contiguous())
-    assert float((y[3:4] - y1).abs().max()) < 1e-5
+    # batch independence up to the summation order: at batch 1 the launches are smaller and other kernels are selected (conv1 as a launch
+    # of its own instead of riding in the global-branch epilogue); the 16-bit-mantissa products of bf16x3 make that visible
+    assert float((y[3:4] - y1).abs().max()) < {L.PREC_F32: 1e-5, L.PREC_F16X3: 3e-5, L.PREC_BF16X3: 3e-4}[gen.precision]
     assert torch.equal(gen(xd), y)
     assert bool(torch.isfinite(y).all()) and float(y.min()) >= 0 and float(y.max()) <= 1
     err = (y.cpu() - ref).abs().amax(dim=(1, 2, 3))
