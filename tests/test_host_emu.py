@@ -205,52 +205,76 @@ def test_generator_fp16_activation_path(small):
 
 def test_conv1_rides_in_the_global_branch_epilogue():
     """SpectralTransform.conv1 of every FFC layer but the first is computed in the epilogue of the launch that produces its input
-    (lama_conv2d_args.fuse1_*, big-lama channel counts only): same result as the stand-alone launches, one pointwise launch per
-    forward instead of one per layer, and the stand-alone path is taken again where the fused launch is refused."""
+    (lama_conv2d_args.fuse1_*, big-lama channel counts only).  Two resnet blocks at 512 = (128 | 384) channels, chained the way the
+    generator's plan chains them: same result as the stand-alone launches (and the oracle), one pointwise conv1 launch instead of four,
+    both split back ends; the exact-fp32 path never fuses."""
+    import torch.nn as nn
     from lama_amd import _lib as L
-    cfg = O.small_config(ngf=64, n_blocks=2)                 # 512 channels at the bottleneck: (128 | 384) like big-lama
-    sd = O.make_synthetic_state_dict(cfg, seed=5, calib_hw=32)
-    gen = make_generator(None, kind='ffc_resnet', **cfg)
-    gen.load_state_dict(sd, strict=True)
+    torch.manual_seed(0)
+    kw = dict(padding_type='reflect', norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU, ratio_gin=0.75, ratio_gout=0.75, enable_lfu=False)
+    blocks = [F.FFCResnetBlock(512, **kw) for _ in range(2)]
+    g = torch.Generator().manual_seed(3)
+    sd = {}
+    for bi, blk in enumerate(blocks):
+        for m in blk.modules():
+            if isinstance(m, nn.Conv2d):
+                m.weight.data = torch.randn(m.weight.shape, generator=g) / (m.weight[0].numel() ** 0.5)
+            if isinstance(m, nn.BatchNorm2d):
+                m.weight.data = torch.rand(m.weight.shape, generator=g) + 0.5
+                m.bias.data = torch.randn(m.bias.shape, generator=g) * 0.2
+                m.running_mean.data = torch.randn(m.bias.shape, generator=g) * 0.1
+                m.running_var.data = torch.rand(m.bias.shape, generator=g) + 0.5
+        blk.eval()
+        sd.update({f'b{bi}.{k}': v for k, v in blk.state_dict().items()})
     ex = F._Exec(emu_lib())
-    gen.set_exec(ex)
-    batch = O.make_synthetic_batch(1, 32, 40, seed=2)
-    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    for blk in blocks:
+        for m in blk.modules():
+            if isinstance(m, F._HipModule):
+                m._exec = ex
+    x = torch.randn(1, 512, 4, 5, generator=g)
+    spec = dict(ratio_gin=0.75, ratio_gout=0.75)
     with torch.no_grad():
-        ref = O.generator_forward(x, sd, cfg)
+        rl, rg = x[:, :128], x[:, 128:]
+        for bi in range(2):
+            rl, rg = O.ffc_resnet_block(rl, rg, sd, f'b{bi}', spec)
+        ref = torch.cat([rl, rg], 1)
     calls = dict(fused=0, conv1=0)
     real = ex.lib.conv2d
 
-    def counting(xv, wp, yv, b, k, *a, **kw):
-        if kw.get('fuse1') is not None:
+    def counting(xv, wp, yv, b, k, *a, **kw2):
+        if kw2.get('fuse1') is not None:
             calls['fused'] += 1
         if k == 1 and yv.C == 192 and xv.C == 384:
             calls['conv1'] += 1
-        return real(xv, wp, yv, b, k, *a, **kw)
+        return real(xv, wp, yv, b, k, *a, **kw2)
+
+    def run(fuse):
+        calls.update(fused=0, conv1=0)
+        scratch = blocks[0].conv1.make_scratch(x.shape, x.device)
+        a, t, b = x.clone(), torch.empty_like(x), torch.empty_like(x)
+        ready = blocks[0].run(a, t, b, scratch, x1_ready=False, next_block=blocks[1] if fuse else None, fuse=fuse)
+        assert ready == fuse
+        ready = blocks[1].run(b, t, a, scratch, x1_ready=ready, next_block=None, fuse=fuse)
+        assert not ready
+        return a
+
     ex.lib.conv2d = counting
     try:
-        gen.set_precision(L.PREC_F16X3)
-        gen.fuse_conv1 = True
-        calls.update(fused=0, conv1=0)
-        y = gen(x)
-        assert calls == dict(fused=3, conv1=1), calls              # 4 FFC layers: the first conv1 alone, three in epilogues
-        gen.fuse_conv1 = False
-        gen._plans.clear()
-        calls.update(fused=0, conv1=0)
-        y0 = gen(x)
-        assert calls == dict(fused=0, conv1=4), calls
-        assert float((y - y0).abs().max()) < 2e-5 and float((y - ref).abs().max()) < 2e-4, (float((y - y0).abs().max()), float((y - ref).abs().max()))
-        gen._plans.clear()
-        gen.set_precision(L.PREC_BF16X3)                            # the other split back end hosts it as well
-        gen.fuse_conv1 = True
-        calls.update(fused=0, conv1=0)
-        yb = gen(x)
-        assert calls == dict(fused=3, conv1=1) and float((yb - ref).abs().max()) < 5e-4
-        gen._plans.clear()
-        gen.set_precision(L.PREC_F32)                               # exact-fp32 path: never fused
-        st = gen.model[5].conv2.ffc.convg2g
-        st._pack(None)
-        assert st.fuse1_operands(torch.zeros(1, 192, 4, 5)) is None
+        for prec, tol in ((L.PREC_F16X3, 5e-5), (L.PREC_BF16X3, 2e-3)):
+            for blk in blocks:
+                blk.set_precision(prec)
+            y = run(True)
+            assert calls == dict(fused=3, conv1=1), calls          # the first layer's conv1 alone, three in epilogues
+            scale = float(ref.abs().max())
+            assert float((y - ref).abs().max()) < 4 * tol * scale, (float((y - ref).abs().max()), scale)
+            if prec == L.PREC_F16X3:
+                y0 = run(False)
+                assert calls == dict(fused=0, conv1=4), calls
+                assert float((y - y0).abs().max()) < tol * scale, (float((y - y0).abs().max()), scale)
+        for blk in blocks:
+            blk.set_precision(L.PREC_F32)
+        st = blocks[1].conv1.ffc.convg2g
+        blocks[1].conv1._pack()
+        assert st.fuse1_operands(torch.zeros(1, 192, 4, 5)) is None  # exact-fp32 path: never fused
     finally:
         ex.lib.conv2d = real
-        gen.set_precision(L.PREC_F16X3)
