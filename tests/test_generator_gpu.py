@@ -232,6 +232,19 @@ def test_odd_sized_input_generic_fft(big):
     assert float((gen(x.cuda()).cpu() - ref).abs().max()) < TOL
 
 
+def test_photo_sized_input(big):
+    """1080 x 1920 (a photo; bottleneck planes 135 x 240: the generic DFT kernels with their one Cooley-Tukey split per length, and 254
+    pixel tiles per launch, i.e. conv1 riding in the global-branch epilogues) against the oracle, at 1.5x the 512^2 tolerance like
+    the other high-resolution cases."""
+    cfg, sd, gen, TOL = big
+    if gen.precision != L.PREC_F16X3:
+        pytest.skip('one precision is enough for this 2 M-pixel oracle pass')
+    x, ref = _oracle_big(1, 1080, 1920, 77)
+    y = gen(x.cuda()).cpu()
+    gen._plans.clear()
+    assert float((y - ref).abs().max()) < 1.5 * TOL, float((y - ref).abs().max())
+
+
 def test_predict_cli_end_to_end(tmp_path):
     """python -m lama_amd.predict on a checkpoint directory (config.yaml with unresolved interpolations + models/best.ckpt) and a
     folder of PNGs: same on-disk contract as bin/predict.py; results within 1 u8 level of the oracle's batch-1 predict loop."""
