@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 104
+#define LAMA_HIP_VERSION 105
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -101,7 +101,12 @@ typedef struct lama_conv2d_args {
     const void* fuse1_w;
     const float* fuse1_bias;
     lama_tensor fuse1_y;
+    /* LAMA_CONV_* bits.  LAMA_CONV_COOPERATIVE: another stream has work for this GPU while this launch runs (the spectral branch of the
+     * same FFC layer): kernels that would fill every CU's register file (the local 3x3 conv: two waves per SIMD) take a geometry that
+     * leaves room for the other stream's workgroups (one 4-wave workgroup per CU) -- a few per cent slower alone, faster together. */
+    int32_t flags;
 } lama_conv2d_args;
+#define LAMA_CONV_COOPERATIVE 1
 
 /* order[k] = the input channel of conv1 that sits at packed K position k (0 <= k < 384) of lama_conv2d_args.fuse1_w */
 void lama_fuse1_channel_order(int32_t* order);

@@ -15,8 +15,9 @@ import torch
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
+CONV_COOPERATIVE = 1
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 104      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 105      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -45,7 +46,8 @@ class Conv2dArgs(C.Structure):
                 ('pad_mode', C.c_int32), ('transposed', C.c_int32),
                 ('x2', Tensor4), ('w2_packed', C.c_void_p), ('bias', C.c_void_p), ('act', C.c_int32),
                 ('resid', Tensor4), ('y', Tensor4), ('batch', C.c_int32), ('precision', C.c_int32),
-                ('range_flag', C.c_void_p), ('fuse1_w', C.c_void_p), ('fuse1_bias', C.c_void_p), ('fuse1_y', Tensor4)]
+                ('range_flag', C.c_void_p), ('fuse1_w', C.c_void_p), ('fuse1_bias', C.c_void_p), ('fuse1_y', Tensor4),
+                ('flags', C.c_int32)]
 
 
 def view(t: Optional[torch.Tensor], c0: int = 0, c: Optional[int] = None) -> Tensor4:
@@ -166,7 +168,7 @@ class LamaLib:
                pad_mode: int = PAD_REFLECT, transposed: bool = False, bias: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, resid: Optional[Tensor4] = None, x2: Optional[Tensor4] = None,
                w2_packed: Optional[torch.Tensor] = None, precision: int = PREC_F32, stream: int = 0,
-               range_flag: Optional[torch.Tensor] = None, fuse1: Optional[tuple] = None):
+               range_flag: Optional[torch.Tensor] = None, fuse1: Optional[tuple] = None, cooperative: bool = False):
         """``fuse1`` = (packed conv1 weights with the channel order of fuse1_channel_order(), BatchNorm shift [192], x1 view): the NEXT
         layer's SpectralTransform.conv1 in the epilogue of this (global-branch) launch -- lama_conv2d_args.fuse1_*."""
         a = Conv2dArgs()
@@ -183,6 +185,7 @@ class LamaLib:
         a.range_flag = None if range_flag is None else range_flag.data_ptr()
         if fuse1 is not None:
             a.fuse1_w, a.fuse1_bias, a.fuse1_y = fuse1[0].data_ptr(), fuse1[1].data_ptr(), fuse1[2]
+        a.flags = CONV_COOPERATIVE if cooperative else 0      # another stream runs beside this launch (lama_conv2d_args.flags)
         self.check(self._l.lama_conv2d_fwd(stream, C.byref(a)), 'lama_conv2d_fwd')
 
     def fuse1_channel_order(self) -> torch.Tensor:

@@ -107,6 +107,7 @@ class _Exec:
         self._depth = 0
         self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
+        self.cooperative_serial = False   # tests: the one-stream launch order with the overlapped order's kernel geometry (bit-equal results)
 
     @property
     def lib(self) -> L.LamaLib:
@@ -427,12 +428,12 @@ class FFC(_HipModule):
             side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
             spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
             ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
-                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st, cooperative=True)
             main.wait_stream(side)                      # join: t is ready for the global conv
         else:
             spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
             ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
-                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st)
+                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st, cooperative=ex.cooperative_serial)
         # the global branch; by the time it runs this layer's own x1 has been consumed (rfft2 and the x + fu(x) add are upstream of t)
         fuse1 = None
         shape_key = (tuple(src.shape), prec)

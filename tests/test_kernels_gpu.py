@@ -93,6 +93,31 @@ def test_conv2d_big_tiles(lib, shape, prec):
     assert torch.allclose(y.cpu(), ref, atol=3e-4, rtol=1e-4), float((y.cpu() - ref).abs().max())
 
 
+@pytest.mark.parametrize('prec', [L.PREC_F16X3, L.PREC_BF16X3], ids=['f16x3', 'bf16x3'])
+@pytest.mark.parametrize('shape', [(4, 512, 128, 64, 64), (5, 512, 128, 64, 64), (6, 512, 128, 64, 64), (2, 64, 128, 9, 12)],
+                         ids=['c2_256wg', '320wg_on', '384wg_off', 'ragged'])
+def test_conv2d_cooperative_geometry(lib, shape, prec):
+    """LAMA_CONV_COOPERATIVE (lama_hip.h): the local 3x3 conv as one 4-wave workgroup per CU, against torch fp32 and against the plain launch
+    (the two geometries split K differently: same value up to fp32 summation order)."""
+    B, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bias, resid = torch.randn(cout, generator=g), torch.randn(B, cout, H, W, generator=g)
+    ref = _conv_ref(x, w, 1, 1, True, False, bias, 1, resid)
+    xd, bd, rd = x.to(DEV), bias.to(DEV), resid.to(DEV)
+    wp = lib.pack_conv_weight(w.to(DEV), None, precision=prec)
+    ys = []
+    for coop in (False, True):
+        y = torch.full((B, cout, H, W), 7.0, device=DEV)
+        lib.conv2d(L.view(xd), wp, L.view(y), B, 3, 1, 1, L.PAD_REFLECT, False, bd, L.ACT_RELU, L.view(rd), precision=prec,
+                   stream=torch.cuda.current_stream().cuda_stream, cooperative=coop)
+        torch.cuda.synchronize()
+        ys.append(y.cpu())
+        assert torch.allclose(ys[-1], ref, atol=3e-4, rtol=1e-4), (coop, float((ys[-1] - ref).abs().max()))
+    assert float((ys[0] - ys[1]).abs().max()) < (2e-4 if prec == L.PREC_BF16X3 else 2e-5)
+
+
 # Shapes on BOTH sides of every size threshold of the production kernel selection (conv_wreg_host.inc): the specialised kernel
 # just takes the launch / the launch just falls through to the next kernel in line.
 #   gw_try_launch   (persistent pointwise GEMM): C in {192, 384}, rows % 96 == 0, 32-pixel tiles x row groups >= 64
@@ -463,7 +488,13 @@ def test_overlap_streams_bit_identical():
     x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
     assert gen.overlap_streams
     gen.overlap_streams = False
+    plain = gen(x)
+    ex = next(m for m in gen.modules() if hasattr(m, '_exec'))._exec
+    ex.cooperative_serial = True       # the overlapped order launches the local conv with LAMA_CONV_COOPERATIVE: same geometry here
+    gen._plans.clear()
     ref = gen(x)
+    ex.cooperative_serial = False
+    assert float((ref - plain).abs().max()) < 1e-4     # the two geometries differ in fp32 summation order only
     gen._plans.clear()
     gen.overlap_streams = True
     for graph in (False, True):
