@@ -402,6 +402,9 @@ def main():
     model = build_model(device, precision)
     model.generator.use_graph = not args.no_graph
     model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # the generator's default; 0 = serial launch order (A/B runs)
+    from lama_amd import ffc as _ffc
+    _ffc._DEFAULT_EXEC.local_first = bool(int(os.environ.get('LAMA_LOCAL_FIRST', '1')))
+    model.generator.pipeline_local = bool(int(os.environ.get('LAMA_PIPELINE_LOCAL', '0')))   # the generator's default; 1 for A/B runs
     model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '1')))         # the generator's default; 0 for A/B runs
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
@@ -460,6 +463,8 @@ def main():
     if rank == 0:
         model.generator.use_graph = False
         model.generator.overlap_streams = False     # per-kernel events need every launch on the current stream
+        from lama_amd import ffc as _ffc2
+        _ffc2._DEFAULT_EXEC.cooperative_serial = True   # ... of the same kernel geometry as the timed region's (FFC.launch sets the flag when it forks)
         model.generator._plans.clear()
         step(collect=False)                         # rank 0 only: no collective in here (the other ranks are done)
         torch.cuda.synchronize()
@@ -469,6 +474,7 @@ def main():
         torch.cuda.synchronize()
         timer.on = False
         kern = timer.summary()
+        _ffc2._DEFAULT_EXEC.cooperative_serial = False
         model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # back to the timed configuration
         model.generator._plans.clear()
         dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])
@@ -481,9 +487,10 @@ def main():
                         traffic=(pmc_traffic(dom, args.precision) or {}).get('traffic_bytes'), traffic_detail=pmc_traffic(dom, args.precision),
                         avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
                         measured='HIP events around every launch in 3 eager steps in SERIAL launch order (each kernel alone on the GPU; '
-                                 'rocprofv3 of `LAMA_OVERLAP_STREAMS=0 python bench.py`: profiles/r02_kernel_stats.csv).  The timed region runs the '
-                                 'spectral branch on a second stream: the same kernels then take 8-12 % longer each (shared CUs) and the step 3 % less '
-                                 '(profiles/r02_kernel_stats_overlap_on_slow_box.csv, r02_ab_bench_overlap_streams.txt)',
+                                 'with the kernel geometry of the timed region: the local conv as one 4-wave workgroup per CU, LAMA_CONV_COOPERATIVE).  '
+                                 'The timed region runs the spectral branch on a second stream beside the local conv: that conv then takes ~116 us '
+                                 'instead of ~96, the spectral GEMM 48 instead of 25, and the step ~6 % less than in serial order '
+                                 '(per-dispatch timeline: profiles/r02_timeline_overlap_step.txt, DESIGN.md 4.12)',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '

@@ -156,6 +156,8 @@ __device__ __forceinline__ void fft_st4(ActP<true> a, float4 v) {
         py{(typename LamaAct<HF>::T*)(p).y};                                                                         \
     (void)px; (void)ps; (void)py
 
+static inline int lama_side_prio() { static const int v = lama_env_int("LAMA_SIDE_PRIO", 1); return v; }   // profiling tools: 0 = default wave priority
+
 struct FftParams {
     const void* x;       // forward: input planes; inverse: residual (may be null).  fp32 or fp16 elements (template parameter HF of
     long long x_bstride; // the kernels = lama_tensor.dtype of all three tensors); strides are in ELEMENTS
@@ -168,6 +170,8 @@ struct FftParams {
     int nplanes;         // B*C
     int ppw;             // planes per workgroup
     float scale;         // 1/sqrt(h*w)
+    int prio;            // raise the wave priority (s_setprio): these launches are the short links of the spectral branch, which runs beside
+                         // the local 3x3 conv of the other stream on the same SIMDs
     long long* trace;    // profiling tools only (LAMA_FFT_TRACE): 16 int64 per workgroup, 100 MHz ticks at the phase boundaries
 };
 
@@ -578,6 +582,7 @@ __device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, i
 template <bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
     FFT_IO(p);
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* P = tww + w;                       // h == w: one twiddle table
@@ -667,6 +672,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
 template <bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p) {
     FFT_IO(p);
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
     constexpr int per_plane = h * wf;
     float2* tww = reinterpret_cast<float2*>(lama_smem);
@@ -831,6 +837,7 @@ __device__ __forceinline__ void ipn_fft(float2* buf, const float2* tw, int estri
 template <int N, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
     FFT_IO(p);
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     constexpr int h = N, w = N, wf = N / 2 + 1, hh = N / 2, wh = N / 2, RSW = N + 1;
     constexpr int NLD = hh * (w / 4) / LAMA_NTHREADS;          // row-pair float4 items per thread
     constexpr int NUT = hh * wh / LAMA_NTHREADS;               // untangle items per thread
@@ -924,6 +931,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ipn_kernel(FftParams p) {
 template <int N, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ipn_kernel(FftParams p) {
     FFT_IO(p);
+    if (p.prio) __builtin_amdgcn_s_setprio(3);
     constexpr int h = N, w = N, wf = N / 2 + 1, hh = N / 2, wh = N / 2, RSW = N + 1;
     constexpr int per_plane = h * wf;
     constexpr int NUT = hh * wh / LAMA_NTHREADS;
@@ -1485,6 +1493,7 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
         const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
         const bool even = p.nplanes % p.ppw == 0;
         p.trace = hf ? nullptr : fft_trace_buf();
+        p.prio = lama_side_prio();
         if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && spec_al)
             FFT_GO(rfft2_ip64_kernel, (false), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), p);
         else if (p.h == 128 && p.w == 128 && fft_inplace() && spec_al)
@@ -1561,6 +1570,7 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
         const dim3 grid(lama_ceil_div(p.nplanes, p.ppw)), blk(LAMA_NTHREADS);
         const bool even = p.nplanes % p.ppw == 0;
         p.trace = hf ? nullptr : fft_trace_buf();
+        p.prio = lama_side_prio();
         if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && spec_al)
             FFT_GO(irfft2_ip64_kernel, (false), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), p);
         else if (p.h == 128 && p.w == 128 && fft_inplace() && spec_al)

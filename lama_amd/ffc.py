@@ -90,6 +90,24 @@ def _check_input(x: torch.Tensor):
         raise LamaError(f'fp32 (or, with precision f16, fp16) activations expected, got {x.dtype}')
 
 
+class SidePipe:
+    """The second stream of a run of FFC layers, with NO join on the critical path.  Layer i's local conv needs layer
+    i-1's outputs only, and layer i's global launch needs layer i-1's x_l and this layer's spectral branch -- not this layer's local
+    conv.  So the local convs form one chain on ``stream`` (each waits for the previous layer's global launch), the spectral branches
+    and global launches form the other chain on the caller's stream (each global launch waits for the PREVIOUS layer's local conv, an
+    event recorded a whole layer earlier), and the two meet again only at ``join``.  A fork + join around every local conv costs
+    5 + 6.6 us of cross-queue signalling per layer inside a hipGraph (profiles/r02_timeline_overlap_step.txt)."""
+
+    def __init__(self, stream: 'torch.cuda.Stream'):
+        self.stream = stream
+        self.prev_local = None        # event: the last local conv launched on ``stream``
+
+    def join(self):
+        if self.prev_local is not None:
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
+            self.prev_local = None
+
+
 class _Exec:
     """Where kernels run: the loaded library and the stream to launch on.  The default is the in-tree
     gfx950 library on the current torch stream; tests inject the host-emulated build of the same
@@ -107,6 +125,7 @@ class _Exec:
         self._depth = 0
         self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
+        self.local_first = True           # capture order at the fork: the first successor of a hipGraph node stays on its queue
         self.cooperative_serial = False   # tests: the one-stream launch order with the overlapped order's kernel geometry (bit-equal results)
 
     @property
@@ -406,7 +425,8 @@ class FFC(_HipModule):
         """src [B, in_cl+in_cg, H, W] -> dst [B, out_cl+out_cg, Ho, Wo] (x_l | x_g channel-contiguous), as 1 launch (no global
         input) or 6 launches (conv1x1, rfft2, spectral conv1x1, irfft2+add, fused local conv, fused global conv).
 
-        ``side``: optional second HIP stream.  The spectral branch (conv1 -> rfft2 -> spectral 1x1 -> irfft2, HBM/latency
+        ``side``: optional second HIP stream, or a ``SidePipe`` (the local convs of a run of layers as a chain of their own: no
+        join per layer).  With a plain stream the spectral branch (conv1 -> rfft2 -> spectral 1x1 -> irfft2, HBM/latency
         bound, small LDS footprint) then runs on it concurrently with the MFMA-bound local 3x3 conv of the main stream; the
         two join before the global conv that consumes both.  Works inside hipGraph capture (fork/join via events).
 
@@ -423,12 +443,26 @@ class FFC(_HipModule):
             return False
         cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
         spec = f.convg2g
-        if side is not None and src.is_cuda:
+        if isinstance(side, SidePipe) and src.is_cuda:
+            main = torch.cuda.current_stream(src.device)
+            side.stream.wait_stream(main)               # the previous layer's global launch (x_g) -- and every reader of dst's x_l slice
+            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
+                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=side.stream.cuda_stream, cooperative=True)
+            done = torch.cuda.Event()
+            done.record(side.stream)
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
+            if side.prev_local is not None:
+                main.wait_event(side.prev_local)        # the global launch reads x_l written by the previous layer's local conv, and
+            side.prev_local = done                      # overwrites an x_g slice that local convs up to that one have read
+        elif side is not None and src.is_cuda:
             main = torch.cuda.current_stream(src.device)
             side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
-            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
+            if not ex.local_first:
+                spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
             ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
                       None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st, cooperative=True)
+            if ex.local_first:
+                spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
             main.wait_stream(side)                      # join: t is ready for the global conv
         else:
             spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
@@ -806,6 +840,10 @@ class FFCResNetGenerator(_HipModule):
         # SpectralTransform.conv1 of every layer but the first rides in the epilogue of the launch that produces its input (the
         # global branch of the previous layer): 35 of 36 pointwise launches less per forward
         self.fuse_conv1 = True
+        # the local convs of the residual blocks as a chain of their own on the second stream (SidePipe) instead of a fork + join per
+        # layer.  Off: inside a hipGraph ROCm 7.2 spreads that topology over three queues and every edge becomes a ~10 us cross-queue
+        # signal (727 -> 695 images/s, profiles/r02_ab_pipeline_local.txt); bit-identical results either way.
+        self.pipeline_local = False
         # fp16-split range watch (lama_conv2d_args.range_flag): one 4-byte read-back per forward; when an activation beyond 65504
         # (or a NaN) was met the forward is repeated with the 3-term bf16 split (fp32 exponent range) and the generator stays
         # on it.  auto_fallback = False raises LamaRangeError instead.
@@ -896,6 +934,7 @@ class FFCResNetGenerator(_HipModule):
 
         steps = plan['steps']
         x1_ready = False
+        pipe = SidePipe(plan['side']) if (plan['side'] is not None and self.pipeline_local and x.is_cuda) else None
         for i, st in enumerate(steps):
             kind = st[0]
             if kind == 'ffc':
@@ -905,8 +944,10 @@ class FFCResNetGenerator(_HipModule):
             elif kind == 'res':
                 _, lay, s, t, d = st
                 nxt = steps[i + 1][1] if self.fuse_conv1 and i + 1 < len(steps) and steps[i + 1][0] == 'res' else None
-                x1_ready = lay.run(B(s), B(t), B(d), plan['scratch'], side=plan['side'], x1_ready=x1_ready, next_block=nxt,
+                x1_ready = lay.run(B(s), B(t), B(d), plan['scratch'], side=pipe or plan['side'], x1_ready=x1_ready, next_block=nxt,
                                    fuse=self.fuse_conv1)
+                if pipe is not None and (i + 1 == len(steps) or steps[i + 1][0] != 'res'):
+                    pipe.join()                     # the last local conv: everything downstream reads its x_l
             elif kind == 'up':
                 _, lay, s, d, bn, act = st
                 lay.run(B(s), B(d), bn, act)

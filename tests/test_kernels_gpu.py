@@ -497,11 +497,13 @@ def test_overlap_streams_bit_identical():
     assert float((ref - plain).abs().max()) < 1e-4     # the two geometries differ in fp32 summation order only
     gen._plans.clear()
     gen.overlap_streams = True
-    for graph in (False, True):
-        gen.use_graph = graph
-        gen._plans.clear()
-        for _ in range(25):
-            assert torch.equal(gen(x), ref), graph
+    for pipelined in (True, False):        # the local convs as a chain of their own (ffc.SidePipe) / a fork + join around every local conv
+        gen.pipeline_local = pipelined
+        for graph in (False, True):
+            gen.use_graph = graph
+            gen._plans.clear()
+            for _ in range(25):
+                assert torch.equal(gen(x), ref), (pipelined, graph)
 
 
 def _run_f16_case_gpu(lib, case, x_dtype=torch.float16, y_dtype=torch.float16, B=2):

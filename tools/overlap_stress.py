@@ -23,6 +23,7 @@ srcs = [torch.randn(B, 512, H, W, device='cuda') for _ in range(2)]
 resid = torch.randn(B, 512, H, W, device='cuda')
 dst = torch.zeros_like(resid)
 scratch = lay.make_scratch(srcs[0].shape, 'cuda')
+F._DEFAULT_EXEC.cooperative_serial = True      # the overlapped order launches the local conv with LAMA_CONV_COOPERATIVE: same kernel geometry in the serial reference
 refs = []
 for s in srcs:
     lay.run(s, dst, scratch, resid)
