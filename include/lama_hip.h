@@ -103,7 +103,8 @@ typedef struct lama_conv2d_args {
     lama_tensor fuse1_y;
     /* LAMA_CONV_* bits.  LAMA_CONV_COOPERATIVE: another stream has work for this GPU while this launch runs (the spectral branch of the
      * same FFC layer): kernels that would fill every CU's register file (the local 3x3 conv: two waves per SIMD) take a geometry that
-     * leaves room for the other stream's workgroups (one 4-wave workgroup per CU) -- a few per cent slower alone, faster together. */
+     * leaves room for the other stream's workgroups (one 4-wave workgroup per CU, taken when the launch has 224 ... 320 workgroups) -- a few
+     * per cent slower alone, faster together.  Results equal the plain launch up to fp32 summation order. */
     int32_t flags;
 } lama_conv2d_args;
 #define LAMA_CONV_COOPERATIVE 1

@@ -49,9 +49,13 @@ CONV_CASES = [
     dict(cin=32, cout=96, k=3, stride=1, pad=1, H=5, W=6, act=0, bias=False, resid=False, scale=False),    # one chunk, narrow image
     dict(cin=128, cout=100, k=1, stride=1, pad=0, H=9, W=15, act=1, bias=True, resid=True, scale=True),    # flat 1x1, two chunks
     dict(cin=192, cout=200, k=1, stride=1, pad=0, H=12, W=11, act=2, bias=True, resid=False, scale=False),  # odd chunk count
-    # ... LAMA_CONV_COOPERATIVE: one 4-wave workgroup per CU (32-channel chunks, six-deep A ring), row-rolling and plain B reads
-    dict(cin=64, cout=128, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True, coop=True),
-    dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, coop=True),
+    # ... the local conv's geometries by launch size (conv_wreg_host.inc), forced here with LAMA_CW_41: 3 = LAMA_CONV_COOPERATIVE's one
+    # 4-wave workgroup per CU (32-channel chunks, six-deep A ring), 2 = two 4-wave workgroups per CU (16-channel chunks); row-rolling
+    # and plain B reads each
+    dict(cin=64, cout=128, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True, geo=3),
+    dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=3),
+    dict(cin=64, cout=256, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True, geo=2),
+    dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=2),
     # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
     dict(cin=32, cout=128, k=3, stride=2, pad=1, H=16, W=70, act=1, bias=True, resid=False, scale=True),
     dict(cin=64, cout=200, k=3, stride=2, pad=1, H=11, W=37, act=0, bias=False, resid=True, scale=False),
@@ -79,9 +83,11 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'coop' if c.get('coop') else ''}")
-def test_conv2d_emulated(case, prec):
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}")
+def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
+    if case.get('geo'):
+        monkeypatch.setenv('LAMA_CW_41', str(case['geo']))
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)
@@ -97,7 +103,7 @@ def test_conv2d_emulated(case, prec):
     ybuf = torch.full((B, cout + 3, ref.shape[2], ref.shape[3]), 7.0)
     lib.conv2d(L.view(x), wp, L.view(ybuf, 2, cout), B, k, case['stride'], case['pad'],
                L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias, case['act'], None if resid is None else L.view(resid), precision=prec,
-               cooperative=case.get('coop', False))
+               cooperative=case.get('geo') == 3)
     y = ybuf[:, 2:2 + cout]
     assert torch.allclose(y, ref, **CONV_TOL[prec]), float((y - ref).abs().max())
     assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0   # nothing written outside the view

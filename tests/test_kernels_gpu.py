@@ -94,11 +94,13 @@ def test_conv2d_big_tiles(lib, shape, prec):
 
 
 @pytest.mark.parametrize('prec', [L.PREC_F16X3, L.PREC_BF16X3], ids=['f16x3', 'bf16x3'])
-@pytest.mark.parametrize('shape', [(4, 512, 128, 64, 64), (5, 512, 128, 64, 64), (6, 512, 128, 64, 64), (2, 64, 128, 9, 12)],
-                         ids=['c2_256wg', '320wg_on', '384wg_off', 'ragged'])
-def test_conv2d_cooperative_geometry(lib, shape, prec):
-    """LAMA_CONV_COOPERATIVE (lama_hip.h): the local 3x3 conv as one 4-wave workgroup per CU, against torch fp32 and against the plain launch
-    (the two geometries split K differently: same value up to fp32 summation order)."""
+@pytest.mark.parametrize('shape', [(8, 512, 128, 64, 64), (7, 512, 128, 64, 64), (6, 512, 128, 64, 64), (10, 512, 128, 64, 64), (11, 512, 128, 64, 64),
+                                   (16, 256, 128, 64, 64), (2, 64, 128, 9, 12)],
+                         ids=['c2_256wg', '224wg_on', '192wg_off', '320wg_on', '352wg_off', '512wg_two_per_cu', 'small'])
+def test_conv2d_local_conv_geometries(lib, shape, prec):
+    """The local 3x3 conv's geometries by launch size (conv_wreg_host.inc): with LAMA_CONV_COOPERATIVE (lama_hip.h) one 4-wave workgroup
+    per CU from 224 to 320 workgroups; two 4-wave workgroups per CU from 512 on; the 8-wave K-split workgroup otherwise.  Each against torch
+    fp32, and the flagged launch against the plain one (different K splits: same value up to fp32 summation order)."""
     B, cin, cout, H, W = shape
     g = torch.Generator().manual_seed(14)
     x = torch.randn(B, cin, H, W, generator=g)
