@@ -405,7 +405,7 @@ def main():
     from lama_amd import ffc as _ffc
     _ffc._DEFAULT_EXEC.local_first = bool(int(os.environ.get('LAMA_LOCAL_FIRST', '1')))
     model.generator.pipeline_local = bool(int(os.environ.get('LAMA_PIPELINE_LOCAL', '0')))   # the generator's default; 1 for A/B runs
-    model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '1')))         # the generator's default; 0 for A/B runs
+    model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '0')))         # the generator's default; 1 for A/B runs
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
     gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if world > 1 else None

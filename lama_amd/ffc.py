@@ -837,9 +837,11 @@ class FFCResNetGenerator(_HipModule):
         # DESIGN.md 4.3): packed-fp32 VALU instructions with an op_sel swizzle are corrupted by another kernel's MFMA on the same
         # SIMD; the library is now built without them (lama_amd/build.py) and 100 000 overlapped layer runs are bit-identical.
         self.overlap_streams = True
-        # SpectralTransform.conv1 of every layer but the first rides in the epilogue of the launch that produces its input (the
-        # global branch of the previous layer): 35 of 36 pointwise launches less per forward
-        self.fuse_conv1 = True
+        # True: SpectralTransform.conv1 of every layer but the first rides in the epilogue of the launch that produces its input (the
+        # global branch of the previous layer): 35 of 36 pointwise launches less per forward.  Worth -10 us per layer in
+        # serial launch order; off by default since the second stream hides the stand-alone conv1 beside the cooperative local conv
+        # (705 -> 719 images/s without it, profiles/r02_ab_overlap_and_fuse1_final.txt)
+        self.fuse_conv1 = False
         # the local convs of the residual blocks as a chain of their own on the second stream (SidePipe) instead of a fork + join per
         # layer.  Off: inside a hipGraph ROCm 7.2 spreads that topology over three queues and every edge becomes a ~10 us cross-queue
         # signal (727 -> 695 images/s, profiles/r02_ab_pipeline_local.txt); bit-identical results either way.

@@ -143,6 +143,16 @@ def test_biglama_512_batch8_all_images(big):
         assert torch.equal(gen(xd), yg) and float((yg.cpu() - ref).abs().max()) < TOL
     finally:
         gen.use_graph = False
+    # conv1 of the next layer in the global-branch epilogue (optional since 4.12): same values up to summation order
+    gen.fuse_conv1 = True
+    gen._plans.clear()
+    try:
+        yf = gen(xd)
+        assert torch.equal(gen(xd), yf) and float((yf.cpu() - ref).abs().max()) < TOL
+        assert float((yf - y).abs().max()) < {L.PREC_F32: 1e-5, L.PREC_F16X3: 3e-5, L.PREC_BF16X3: 3e-4}[gen.precision]
+    finally:
+        gen.fuse_conv1 = False
+        gen._plans.clear()
 
 
 def test_training_module_properties_at_configs1_size():

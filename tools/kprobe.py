@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run selected bottleneck kernels a few times (for rocprofv3 --pmc passes).  usage: kprobe.py [bf16x3|f32] [names...]
-names: convA convB conv1 fuconv rfft irfft down1 up3 stem head"""
+names: convA convAc convB conv1 fuconv rfft irfft down1 up3 stem head"""
 import os
 import sys
 
@@ -26,7 +26,7 @@ def main():
     def rnd(*s):
         return torch.zeros(*s, device=dev) if zero else torch.randn(*s, generator=g).to(dev)
 
-    def conv(cin, cout, k, H, W, stride=1, tr=False, x2c=0, fuse1=False):
+    def conv(cin, cout, k, H, W, stride=1, tr=False, x2c=0, fuse1=False, coop=False):
         x = rnd(B, cin, H, W)
         wt = rnd(cin, cout, k, k) if tr else rnd(cout, cin, k, k)
         s2 = 2 if tr else stride
@@ -47,13 +47,14 @@ def main():
         resid = rnd(B, cout, Ho, Wo) if fuse1 else None
         return lambda: lib.conv2d(L.view(x), wp, L.view(y), B, k, s2, 1 if tr else k // 2, L.PAD_ZERO if tr else L.PAD_REFLECT, tr, bias,
                                   L.ACT_RELU, None if resid is None else L.view(resid), None if x2 is None else L.view(x2), w2p, precision=prec,
-                                  stream=st, fuse1=None if f1 is None else f1[:3])
+                                  stream=st, fuse1=None if f1 is None else f1[:3], cooperative=coop)
 
     x1 = rnd(B, 192, h, w)
     spec = torch.empty(B, 384, h, w // 2 + 1, device=dev)
     y = torch.empty_like(x1)
     table = {
         'convA': lambda: conv(512, 128, 3, h, w),
+        'convAc': lambda: conv(512, 128, 3, h, w, coop=True),     # LAMA_CONV_COOPERATIVE: one 4-wave workgroup per CU (the geometry of the overlapped step)
         'convB': lambda: conv(128, 384, 3, h, w, x2c=192),
         'convBf': lambda: conv(128, 384, 3, h, w, x2c=192, fuse1=True),
         'convA128': lambda: conv(512, 128, 3, 128, 128),
