@@ -488,9 +488,11 @@ def main():
                         avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
                         measured='HIP events around every launch in 3 eager steps in SERIAL launch order (each kernel alone on the GPU; '
                                  'with the kernel geometry of the timed region: the local conv as one 4-wave workgroup per CU, LAMA_CONV_COOPERATIVE).  '
-                                 'The timed region runs the spectral branch on a second stream beside the local conv: that conv then takes ~116 us '
-                                 'instead of ~96, the spectral GEMM 48 instead of 25, and the step ~6 % less than in serial order '
-                                 '(per-dispatch timeline: profiles/r02_timeline_overlap_step.txt, DESIGN.md 4.12)',
+                                 'rocprofv3 of `LAMA_OVERLAP_STREAMS=0 python bench.py`: profiles/r02_kernel_stats.csv.  The timed region runs the spectral '
+                                 'branch (conv1, rfft2, spectral GEMM, irfft2: ~110 us alone) on a second stream BESIDE the local conv: that conv then '
+                                 'takes ~133 us instead of ~97 with the branch inside that time, and the step is 5 % shorter than in serial order '
+                                 '(rocprofv3 of the default command: profiles/r02_kernel_stats_overlap_on.csv; per-dispatch timeline: '
+                                 'profiles/r02_timeline_overlap_step.txt; DESIGN.md 4.12)',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
