@@ -31,8 +31,8 @@ The JSON line also carries
                    (MIOpen convs, rocFFT rfftn / irfftn) on the same GPU, timed in a subprocess outside the
                    timed region (the oracle's functional restatement moved to cuda; /root/reference does not
                    exist on the GPU box).
-  value_with_h2d_d2h -- the same step fed from pinned host buffers (fp32 image + mask in, u8 out) over PCIe,
-                   copies on the compute stream (not overlapped).  Never `value`.
+  value_with_h2d_d2h -- the same step fed from pinned host buffers (fp32 image + mask in, u8 out) over PCIe: copies on the compute
+                   stream (not overlapped), and `pipelined` (double-buffered, copies on streams of their own).  Never `value`.
 
   configs2_fp16_leg / configs4_refine_leg -- the other single-GPU configs of BASELINE.json (4 x 1024^2 with fp16 activations beside the
                    fp32-accurate default; refine_predict on one 2048^2 image), rank 0, N = 1 only.  Never `value`.
@@ -436,7 +436,7 @@ def main():
 
     # the same K steps fed from / drained to pinned HOST buffers (SURVEY.md 8(d) "includes H2D/D2H"): fp32 image + mask in, u8 out,
     # copies on the compute stream (serial, not overlapped).  Reported beside `value`, never as `value`.
-    dt_pcie = None
+    dt_pcie = dt_piped = dt_piped_graph = None
     if world == 1:
         h_img, h_mask = img.cpu().pin_memory(), mask.cpu().pin_memory()
         h_u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8).pin_memory()
@@ -456,6 +456,61 @@ def main():
             step_pcie()
         torch.cuda.synchronize()
         dt_pcie = time.perf_counter() - t1
+
+        # ... and pipelined the way a serving loop would: double-buffered device inputs / outputs, H2D of batch k+1 and D2H of batch k-1 on
+        # copy streams of their own beside the compute of batch k (what predict.py's loader thread + pinned staging buffers do)
+        s_in, s_out = torch.cuda.Stream(device=device), torch.cuda.Stream(device=device)
+        main = torch.cuda.current_stream(device)
+        dd = [dict(img=torch.empty_like(img), mask=torch.empty_like(mask), u8=torch.empty_like(u8), h=torch.empty_like(h_u8).pin_memory(),
+                   ready=torch.cuda.Event(), computed=torch.cuda.Event(), drained=torch.cuda.Event()) for _ in range(2)]
+
+        def feed(k):
+            b = dd[k & 1]
+            with torch.cuda.stream(s_in):
+                s_in.wait_event(b['computed'])          # the compute that last read this input pair is done
+                b['img'].copy_(h_img, non_blocking=True)
+                b['mask'].copy_(h_mask, non_blocking=True)
+                b['ready'].record(s_in)
+
+        def step_piped(k, last):
+            b = dd[k & 1]
+            if not last:
+                feed(k + 1)
+            main.wait_event(b['ready'])
+            main.wait_event(b['drained'])               # the D2H that last read this u8 buffer is done
+            out = model(dict(image=b['img'], mask=b['mask']))
+            lib.quantize_u8_hwc(L.view(out['inpainted']), b['u8'], BATCH, RES, RES, main.cuda_stream)
+            b['computed'].record(main)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(b['computed'])
+                b['h'].copy_(b['u8'], non_blocking=True)
+                b['drained'].record(s_out)
+
+        def run_piped():
+            for b in dd:
+                b['computed'].record(main)
+                b['drained'].record(main)
+            feed(0)
+            step_piped(0, False)
+            step_piped(1, True)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            feed(0)
+            for k in range(args.steps):
+                step_piped(k, k + 1 == args.steps)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            assert torch.equal(dd[(args.steps - 1) & 1]['h'], h_u8)      # same images as the serial leg
+            return dt2
+
+        dt_piped_graph = None if args.no_graph else run_piped()
+        # ROCm 7.2: a hipGraph replay does not run beside the copies of other streams (nor beside another graph), so the
+        # pipeline only pays with plain launches -- which cost ~2 % of the step
+        model.generator.use_graph = False
+        model.generator._plans.clear()
+        dt_piped = run_piped()
+        model.generator.use_graph = not args.no_graph
+        model.generator._plans.clear()
 
     # instrumented eager steps: per-kernel durations with HIP events on the launch stream
     roof = roof_ffc = None
@@ -589,7 +644,14 @@ def main():
             'value_with_h2d_d2h': None if dt_pcie is None else dict(
                 value=round(BATCH * args.steps / dt_pcie, 3), unit='images/s', ms_per_step=round(dt_pcie / args.steps * 1e3, 3),
                 note=f'pinned host fp32 image+mask in ({BATCH * 4 * RES * RES * 4 / 1e6:.1f} MB), u8 out ({BATCH * 3 * RES * RES / 1e6:.1f} MB) '
-                     'per step over PCIe on the compute stream, not overlapped'),
+                     'per step over PCIe on the compute stream, not overlapped',
+                pipelined=None if dt_piped is None else dict(
+                    value=round(BATCH * args.steps / dt_piped, 3), unit='images/s', ms_per_step=round(dt_piped / args.steps * 1e3, 3),
+                    hip_graph=False,
+                    with_hip_graph=None if dt_piped_graph is None else round(BATCH * args.steps / dt_piped_graph, 3),
+                    note='the same host buffers, double-buffered on the device: H2D of batch k+1 and D2H of batch k-1 on copy streams of their own '
+                         'beside the compute of batch k, plain launches; outputs equal the serial leg bit for bit.  with_hip_graph: the same loop '
+                         'around graph replays -- on ROCm 7.2 a replay does not run beside the copies of other streams, so nothing is hidden')),
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['total_us'])},
         }
         print(json.dumps(line), flush=True)
