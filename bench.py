@@ -574,6 +574,32 @@ def main():
             roof_ffc = dict(unit_of_work=f'FourierUnit forward [{BATCH},192,{h},{h}] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
                             peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=ffc_traffic,
                             avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg)
+            try:    # the coarser units beside it (serial-order kernel sums; MFMA utilisation is their primary figure)
+                def us(prefix):
+                    ks = [k for k in kern if k.startswith(prefix)]
+                    return kern[ks[0]]['avg_us'] if ks else None
+                t_c1 = us(f'conv1x1_cin384_cout192_{h}x{h}')
+                t_loc = us(f'conv3x3_cin512_cout128_{h}x{h}')
+                t_glb = us(f'conv3x3_cin128_cout384_{h}x{h}+1x1_cin192')
+                if None not in (t_c1, t_loc, t_glb):
+                    px = BATCH * h * h
+                    st_us = t_c1 + kern[fu]['avg_us']                       # conv2 rides in the global launch (counted there)
+                    lay_us = st_us + t_loc + t_glb
+                    st_b = 2 * BATCH * 384 * h * h * 4 + (2 * 384 * 192 + 384 * 384) * 4
+                    lay_b = 2 * BATCH * 512 * h * h * 4 + 1329280 * 4
+                    lay_f = 2.0 * px * (512 * 128 * 9 + 128 * 384 * 9 + 384 * 192 + 192 * 384) + 2.0 * BATCH * h * (h // 2 + 1) * 384 * 384
+                    roof_ffc['other_units'] = {
+                        'SpectralTransform (conv1 + FourierUnit; conv2 is a K-segment of the global launch)': dict(
+                            us=round(st_us, 1), algorithmic_bytes=st_b, hbm_frac=round(st_b / st_us / 1e3 / HBM_PEAK_GBS, 4)),
+                        'FFC_BN_ACT (5 launches, serial order)': dict(
+                            us=round(lay_us, 1), algorithmic_bytes=lay_b, hbm_frac=round(lay_b / lay_us / 1e3 / HBM_PEAK_GBS, 4),
+                            gflop=round(lay_f / 1e9, 1), mfma_tflops=round(lay_f / lay_us / 1e6, 1),
+                            mfma_frac=round(lay_f / lay_us / 1e6 / (MFMA_F32_PEAK_TF if precision == L.PREC_F32 else MFMA_BF16_PEAK_TF / 3.0), 4)),
+                        'FFCResnetBlock (2 layers)': dict(us=round(2 * lay_us, 1), algorithmic_bytes=2 * BATCH * 512 * h * h * 4 + 2 * 1329280 * 4,
+                                                         gflop=round(2 * lay_f / 1e9, 1)),
+                    }
+            except Exception as e:      # noqa: BLE001  (never lose the bench line over a derived figure)
+                roof_ffc['other_units'] = dict(error=repr(e)[:200])
 
     # extra leg (rank 0, N = 1): the same step on the exact-fp32 MFMA path, for reference beside the default bf16x3 split
     f32_leg = None
