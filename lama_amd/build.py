@@ -93,13 +93,17 @@ def build(force: bool = False, verbose: bool = True, profiling: bool = True) -> 
     """Compile every HIP source for gfx950 and link lama_amd/lib/liblama_hip.so (the product) and, with ``profiling``,
     lama_amd/lib/liblama_hip_prof.so (same sources + -DLAMA_PROFILING, for tools/ and the forced-path tests); returns the
     product's path."""
-    if not profiling:
-        return _build_one(LIB, [], force, verbose)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
-        f1 = ex.submit(_build_one, LIB, [], force, verbose)
-        f2 = ex.submit(_build_one, LIB_PROF, ['-DLAMA_PROFILING'], force, verbose, PROF_ONLY_SOURCES)
-        f2.result()
-        return f1.result()
+    import fcntl
+    os.makedirs(LIBDIR, exist_ok=True)
+    with open(os.path.join(LIBDIR, '.build.lock'), 'w') as lock:      # several processes may get here at once (pytest -n, torchrun ranks)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not profiling:
+            return _build_one(LIB, [], force, verbose)
+        with concurrent.futures.ThreadPoolExecutor(max_workers=2) as ex:
+            f1 = ex.submit(_build_one, LIB, [], force, verbose)
+            f2 = ex.submit(_build_one, LIB_PROF, ['-DLAMA_PROFILING'], force, verbose, PROF_ONLY_SOURCES)
+            f2.result()
+            return f1.result()
 
 
 if __name__ == '__main__':

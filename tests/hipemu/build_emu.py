@@ -19,7 +19,14 @@ def _cxx():
 
 
 def build(force=False):
+    import fcntl
     os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, '.build.lock'), 'w') as lock:      # pytest-xdist workers get here at the same time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build(force)
+
+
+def _build(force):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip') and f != 'debug_probes.hip')
     deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'),
                    os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h'),
