@@ -11,8 +11,8 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """The CPU suite (-m "not gpu": 240 emulator / oracle / host tests, 8 minutes on one core) runs on four pytest-xdist workers when
-    xdist is installed and nothing else was asked for; the GPU suite never does (one process owns the GPU, and the co-residency tests
+    """The CPU suite (-m "not gpu": 246 emulator / oracle / host tests, 17 minutes on one core, 3 on eight) runs on up to eight
+    pytest-xdist workers (one per core) when xdist is installed and nothing else was asked for; the GPU suite never does (one process owns the GPU, and the co-residency tests
     must not share it)."""
     if os.environ.get('PYTEST_XDIST_WORKER') or hasattr(config, 'workerinput'):     # a worker runs this hook too: it must never spawn workers
         return None
@@ -21,7 +21,7 @@ def pytest_cmdline_main(config):
         return None
     if os.environ.get('LAMA_TEST_WORKERS', '') == '0' or not config.pluginmanager.hasplugin('xdist'):
         return None
-    n = int(os.environ.get('LAMA_TEST_WORKERS', '4'))
+    n = int(os.environ.get('LAMA_TEST_WORKERS', str(min(8, os.cpu_count() or 1))))
     opt.numprocesses, opt.dist, opt.tx = n, 'load', ['popen'] * n
     return None
 
