@@ -379,14 +379,17 @@ def main():
         return cpu_one_thread_leg()
     if args.eager_leg:
         return eager_leg()
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or bool(int(os.environ.get('LAMA_BENCH_FORCE_DIST', '0')))):
         raise SystemExit(spawn_ranks(args, sys.argv[1:]))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    # LAMA_BENCH_FORCE_DIST=1: take the RCCL path (process group, all-gather, barrier, MAX all-reduce) with ONE rank too -- the only way to
+    # exercise it on a single-GPU box (launched through torch.distributed.run --nproc-per-node 1)
+    use_dist = world > 1 or (bool(int(os.environ.get('LAMA_BENCH_FORCE_DIST', '0'))) and 'RANK' in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
@@ -408,16 +411,16 @@ def main():
     model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '0')))         # the generator's default; 1 for A/B runs
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
-    gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if world > 1 else None
+    gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if use_dist else None
 
     def step(collect=True):
         out = model(dict(image=img, mask=mask))
         lib.quantize_u8_hwc(L.view(out['inpainted']), u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
-        if world > 1 and collect:
+        if use_dist and collect:
             dist.all_gather_into_tensor(gathered, u8)       # the only data-path collective: output images
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -429,7 +432,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -657,7 +660,7 @@ def main():
         total_images = world * BATCH * args.steps
         line = {
             'metric': f'inpainted images/sec at {RES}x{RES} big-lama',
-            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'n_ranks_seen': (dist.get_world_size() if world > 1 else 1),
+            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'n_ranks_seen': (dist.get_world_size() if use_dist else 1),
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if precision == L.PREC_F32 else f'f32 (3-term {args.precision[:-2]} split on the 16-bit MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',
@@ -681,7 +684,7 @@ def main():
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['total_us'])},
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()                  # rank 0 is still busy with its roofline section when the others get here
         dist.destroy_process_group()
 
