@@ -56,6 +56,11 @@ CONV_CASES = [
     dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=3),
     dict(cin=64, cout=256, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True, geo=2),
     dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=2),
+    # ... ConvTranspose2d as four output-parity classes on the weights-in-registers kernel (cwt_try_launch: cin % 64 == 0, cout % 128 == 0),
+    # forced at any launch size with LAMA_CWT=2; ragged tiles, narrow image (16-pixel tile rows), two M tiles, two 64-channel chunks
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=6, W=35, act=1, bias=True, resid=False, scale=True, transposed=True, cwt=2),
+    dict(cin=128, cout=256, k=3, stride=2, pad=1, H=9, W=10, act=0, bias=False, resid=False, scale=False, transposed=True, cwt=2),
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=6, W=35, act=1, bias=True, resid=False, scale=True, transposed=True, cwt=0),   # the fused launch on the same shape
     # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
     dict(cin=32, cout=128, k=3, stride=2, pad=1, H=16, W=70, act=1, bias=True, resid=False, scale=True),
     dict(cin=64, cout=200, k=3, stride=2, pad=1, H=11, W=37, act=0, bias=False, resid=True, scale=False),
@@ -83,11 +88,13 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}")
 def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
     if case.get('geo'):
         monkeypatch.setenv('LAMA_CW_41', str(case['geo']))
+    if 'cwt' in case:
+        monkeypatch.setenv('LAMA_CWT', str(case['cwt']))
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)
