@@ -42,9 +42,11 @@ DEV = 'cuda'
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}")
-def test_conv2d(anylib, case, prec):
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}")
+def test_conv2d(anylib, case, prec, monkeypatch):
     lib = anylib
+    if 'cwt' in case:       # ConvTranspose2d as four parity-class launches: a switch of the profiling build (the product keeps the fused launch)
+        monkeypatch.setenv('LAMA_CWT', str(case['cwt']))
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)
