@@ -536,6 +536,12 @@ def main():
         model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # back to the timed configuration
         model.generator._plans.clear()
         dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])
+        # the two bottleneck 3x3 launches are within a few per cent of each other in serial order and which one leads flipped from run to
+        # run: among the kernels within 5 % of the leader take the one with the most algorithmic FLOPs per step (the local conv -- also the
+        # top kernel of the timed region's own rocprofv3 summary, profiles/r02_close_kernel_stats_overlap_on.csv); the other is `runner_up`
+        near = [k for k in kern if k.startswith('conv') and timer.flops.get(k) and kern[k]['total_us'] >= 0.95 * kern[dom]['total_us']]
+        if len(near) > 1:
+            dom = max(near, key=lambda k: timer.flops[k] * kern[k]['n'])
         h = RES // 8
         flops = timer.flops.get(dom)
         peak = MFMA_F32_PEAK_TF if precision == L.PREC_F32 else MFMA_BF16_PEAK_TF / 3.0
