@@ -11,7 +11,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """The CPU suite (-m "not gpu": 246 emulator / oracle / host tests, 17 minutes on one core, 3 on eight) runs on up to eight
+    """The CPU suite (-m "not gpu": 255 emulator / oracle / host tests, 20 minutes on one core, 3.5 on eight) runs on up to eight
     pytest-xdist workers (one per core) when xdist is installed and nothing else was asked for; the GPU suite never does (one process owns the GPU, and the co-residency tests
     must not share it)."""
     if os.environ.get('PYTEST_XDIST_WORKER') or hasattr(config, 'workerinput'):     # a worker runs this hook too: it must never spawn workers
