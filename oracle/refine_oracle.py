@@ -6,9 +6,13 @@ leg may import this module; the product (lama_amd/refinement.py) never does.
 
 Third-party pieces.  refinement.py calls ``kornia.filters.gaussian_blur2d``, ``kornia.geometry.transform.resize``,
 ``kornia.morphology.erosion`` and ``cv2.getStructuringElement`` -- neither kornia (reference pins kornia==0.5.0,
-requirements.txt) nor opencv is installed in this image, so their published algorithms are restated here and
-**parity of these four helpers is unpinned** (no reference-run fixture can be generated offline); everything built on
-torch (F.interpolate, F.pad, Adam, autograd through the generator) is the real thing:
+requirements.txt) nor opencv is installed in this image, so their published algorithms are restated here.  No reference-run
+fixture can be generated offline; the four helpers are instead pinned by **known-answer vectors worked from the cited sources**
+(tests/test_refine_helpers_known_answers.py: the 5-tap sigma = 1 window as literals, an impulse / border response of the blur,
+OpenCV's documented 5 x 5 ellipse and the 15 x 15 one as a literal matrix, hand-worked erosions incl. the non-eroding border and
+the agreement of kornia 0.5.0's conv formulation with the later unfold formulation on masks, hand-worked half-pixel bilinear
+cases), and the HIP kernels replay the same vectors.  Everything built on torch (F.interpolate, F.pad, Adam, autograd through
+the generator) is the real thing:
 
   * gaussian_blur2d(x, (5,5), (1,1)): kornia.filters.gaussian -- 1-D window exp(-x^2 / (2 sigma^2)), x = -2..2, normalised to
     sum 1; 2-D kernel = outer product; ``filter2d(border_type='reflect')`` = F.pad(mode='reflect') + depthwise correlation.
@@ -196,8 +200,10 @@ def get_image_mask_pyramid(image: Tensor, mask: Tensor, unpad_to_size, min_side:
 
 
 def refine_predict(image: Tensor, mask: Tensor, unpad_to_size, sd, cfg: dict, modulo: int = 8, n_iters: int = 15, lr: float = 0.002,
-                   min_side: int = 512, max_scales: int = 3, px_budget: int = 1800000, prefix: str = 'model.') -> Tensor:
-    """refinement.py:228-314 on one device: image [1,3,H,W], mask [1,1,H,W] -> inpainted [1,3,h,w]."""
+                   min_side: int = 512, max_scales: int = 3, px_budget: int = 1800000, prefix: str = 'model.',
+                   trace: Optional[list] = None) -> Tensor:
+    """refinement.py:228-314 on one device: image [1,3,H,W], mask [1,1,H,W] -> inpainted [1,3,h,w].  ``trace`` (optional list)
+    receives one dict per scale: the per-iteration losses of ``infer`` and the scale's inpainted image."""
     ls_images, ls_masks = get_image_mask_pyramid(image, mask, unpad_to_size, min_side, max_scales, px_budget)
     image_inpainted = None
     for img, msk in zip(ls_images, ls_masks):
@@ -205,6 +211,10 @@ def refine_predict(image: Tensor, mask: Tensor, unpad_to_size, sd, cfg: dict, mo
         img = pad_tensor_to_modulo(img, modulo)
         msk = pad_tensor_to_modulo(msk, modulo)
         msk = (msk >= 1e-8).to(msk.dtype)
-        image_inpainted = infer(img, msk, sd, cfg, image_inpainted, orig_shape, n_iters, lr, prefix)
+        tr = {} if trace is not None else None
+        image_inpainted = infer(img, msk, sd, cfg, image_inpainted, orig_shape, n_iters, lr, prefix, trace=tr)
         image_inpainted = image_inpainted[:, :, :orig_shape[0], :orig_shape[1]]
+        if trace is not None:
+            tr['out'] = image_inpainted
+            trace.append(tr)
     return image_inpainted
