@@ -349,6 +349,15 @@ def configs2_leg(model, device, lib, args):
     return out
 
 
+def spawn_command(gpus, argv, port):
+    """The torch.distributed.run command line of `python bench.py --gpus N` (one rank per GPU of ONE node, rendezvous on 127.0.0.1) and
+    the environment it needs (dmabuf IPC for RCCL)."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(gpus)}', '--master-addr', '127.0.0.1',
+           '--master-port', str(int(port)), os.path.abspath(__file__), *argv]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return cmd, env
+
+
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a torch.distributed environment: re-execute under torch.distributed.run (one rank per GPU)."""
     import socket
@@ -356,9 +365,7 @@ def spawn_ranks(args, argv):
     with socket.socket() as so:
         so.bind(('127.0.0.1', 0))
         port = so.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__), *argv]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd, env = spawn_command(args.gpus, argv, port)
     return subprocess.call(cmd, env=env)
 
 
@@ -394,8 +401,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
-    if args.gpus != world and rank == 0:
-        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus = {world}', file=sys.stderr)
+    if args.gpus != world:
+        # the line's n_gpus must be the number of ranks that actually ran: a mismatch between the flag and the launcher is an error,
+        # not something to report around
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run '
+                         f'`python bench.py --gpus {args.gpus}` without a torch.distributed environment and it spawns the ranks itself)')
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     precision = L.PREC_NAMES[args.precision]
@@ -411,16 +421,37 @@ def main():
     model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '0')))         # the generator's default; 1 for A/B runs
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
-    gathered = torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if use_dist else None
+    # The only data-path collective: the u8 output images (6.3 MB per rank).  It runs OFF the compute stream: the u8 batch of step k is
+    # gathered (RCCL's own stream, ordered behind a side stream that waits for step k's quantize kernel) while step k + 1 computes;
+    # two (u8, gathered) buffer pairs, step k + 2 waits for gather k before it overwrites the pair.  Every gather is inside the timed
+    # region: the closing barrier() synchronises the device, which drains the last two.
+    u8_ring = [u8, torch.empty_like(u8)] if use_dist else [u8]
+    gathered = [torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) for _ in range(2)] if use_dist else None
+    comm_stream = torch.cuda.Stream(device=device) if use_dist else None
+    quantized = [torch.cuda.Event() for _ in range(2)] if use_dist else None
+    gather_work = [None, None]
+    step_no = [0]
 
     def step(collect=True):
+        k = step_no[0] & 1 if (use_dist and collect) else 0
+        main = torch.cuda.current_stream(device)
+        if use_dist and collect and gather_work[k] is not None:
+            gather_work[k].wait()                           # device-side: the compute stream waits for gather k - 2 (long done) before reusing its buffers
+            gather_work[k] = None
         out = model(dict(image=img, mask=mask))
-        lib.quantize_u8_hwc(L.view(out['inpainted']), u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
+        lib.quantize_u8_hwc(L.view(out['inpainted']), u8_ring[k], BATCH, RES, RES, main.cuda_stream)
         if use_dist and collect:
-            dist.all_gather_into_tensor(gathered, u8)       # the only data-path collective: output images
+            quantized[k].record(main)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(quantized[k])
+                gather_work[k] = dist.all_gather_into_tensor(gathered[k], u8_ring[k], async_op=True)
+            step_no[0] += 1
 
     def barrier():
         if use_dist:
+            for w_ in gather_work:
+                if w_ is not None:
+                    w_.wait()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -663,10 +694,12 @@ def main():
             eager = dict(error=repr(e)[:300])
 
     if rank == 0:
+        n_seen = dist.get_world_size() if use_dist else 1
+        assert n_seen == world == args.gpus, (n_seen, world, args.gpus)      # every rank of --gpus took part in the timed region
         total_images = world * BATCH * args.steps
         line = {
             'metric': f'inpainted images/sec at {RES}x{RES} big-lama',
-            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'n_ranks_seen': (dist.get_world_size() if use_dist else 1),
+            'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'n_ranks_seen': n_seen,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32' if precision == L.PREC_F32 else f'f32 (3-term {args.precision[:-2]} split on the 16-bit MFMA, fp32 accumulate, fp32 activations)', 'data': 'synthetic',

@@ -24,13 +24,18 @@ _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libl
 
 
 class LamaError(RuntimeError):
-    pass
+    """``code``: the numeric return value of the C entry point (LAMA_ERR_* < 0, hipError_t > 0) or None for host-side errors."""
+
+    def __init__(self, msg: str = '', code=None):
+        super().__init__(msg)
+        self.code = code
 
 
 class LamaRangeError(LamaError):
     """A weight or an activation left the range of the fp16 split (|x| <= 65504): re-run with PREC_BF16X3 / PREC_F32."""
 
 F16_MAX = 65504.0
+ERR_BAD_ARG, ERR_UNSUPPORTED, ERR_WORKSPACE = -1, -2, -3      # include/lama_hip.h LAMA_ERR_*
 
 
 class Tensor4(C.Structure):
@@ -126,7 +131,7 @@ class LamaLib:
     # -- helpers -------------------------------------------------------------------------------
     def check(self, rc: int, what: str):
         if rc != 0:
-            raise LamaError(f'{what} failed: {self._l.lama_error_string(rc).decode()} (code {rc})')
+            raise LamaError(f'{what} failed: {self._l.lama_error_string(rc).decode()} (code {rc})', code=int(rc))
 
     @staticmethod
     def stream_of(t: torch.Tensor) -> int:

@@ -186,10 +186,19 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void gauss5_bwd_kernel(GaussParams p
         float acc = 0.0f;
         if (y < p.H && x < p.W) {
             const float* gy = p.x + b * p.x_bs + (long long)c * p.H * p.W;
-            for (int py = -2; py < p.H + 2; ++py) {
-                if (rf_reflect(py, p.H) != y) continue;
-                for (int px = -2; px < p.W + 2; ++px) {
-                    if (rf_reflect(px, p.W) != x) continue;
+            // padded positions that reflect onto row y: y itself, its mirror about row 0 (-y, for 1 <= y <= 2) and its mirror about
+            // row H - 1 (2 (H - 1) - y, for H - 3 <= y <= H - 2) -- at most three, enumerated directly; the same for columns
+            int pys[3], pxs[3], ny = 0, nx = 0;
+            pys[ny++] = y;
+            if (y >= 1 && y <= 2) pys[ny++] = -y;
+            if (y >= p.H - 3 && y <= p.H - 2) pys[ny++] = 2 * (p.H - 1) - y;
+            pxs[nx++] = x;
+            if (x >= 1 && x <= 2) pxs[nx++] = -x;
+            if (x >= p.W - 3 && x <= p.W - 2) pxs[nx++] = 2 * (p.W - 1) - x;
+            for (int iy = 0; iy < ny; ++iy) {
+                const int py = pys[iy];
+                for (int ix = 0; ix < nx; ++ix) {
+                    const int px = pxs[ix];
                     // output pixels q = (py - dy, px - dx) that read padded position (py, px) with weight k[dy] k[dx]
                     for (int dy = -2; dy <= 2; ++dy) {
                         const int qy = py - dy;

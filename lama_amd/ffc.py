@@ -485,7 +485,7 @@ class FFC(_HipModule):
                 ex.conv2d(*gargs, fuse1=fuse1, **gkw)
                 return True
             except LamaError as e:
-                if 'unsupported' not in str(e):
+                if e.code != L.ERR_UNSUPPORTED:
                     raise
                 ex.no_fuse1.add(shape_key)    # e.g. planes too small for the 12 x 1 launch: at this shape conv1 stays a launch of its own
         ex.conv2d(*gargs, **gkw)

@@ -48,17 +48,31 @@ REFINER_DEFAULTS = {'refiner.gpu_ids': '0,', 'refiner.modulo': 8, 'refiner.n_ite
                     'refiner.max_scales': 3, 'refiner.px_budget': 1800000}     # configs/prediction/default.yaml:16-24
 
 
-def _parse_value(v: str):
-    if v.lower() in ('true', 'false'):
-        return v.lower() == 'true'
-    try:
-        return int(v)
-    except ValueError:
-        pass
-    try:
-        return float(v)
-    except ValueError:
+# option types: paths, suffixes and names stay strings whatever they look like (indir=2024, model.checkpoint=100 are a directory and
+# a file name); everything else is a bool / int / float as in the YAML defaults
+STRING_KEYS = {'model.path', 'model.checkpoint', 'indir', 'outdir', 'device', 'dataset.kind', 'dataset.img_suffix', 'out_ext', 'out_key',
+               'precision', 'refiner.gpu_ids'}
+BOOL_KEYS = {'refine'}
+INT_KEYS = {'dataset.pad_out_to_modulo', 'batch_size', 'refiner.modulo', 'refiner.n_iters', 'refiner.min_side', 'refiner.max_scales',
+            'refiner.px_budget'}
+FLOAT_KEYS = {'refiner.lr'}
+
+
+def _parse_value(k: str, v: str):
+    if k in STRING_KEYS:
         return v
+    try:
+        if k in BOOL_KEYS:
+            if v.lower() not in ('true', 'false'):
+                raise ValueError(v)
+            return v.lower() == 'true'
+        if k in INT_KEYS:
+            return int(v)
+        if k in FLOAT_KEYS:
+            return float(v)
+    except ValueError:
+        raise SystemExit(f'{k}={v!r}: expected a {"bool" if k in BOOL_KEYS else "number"}')
+    raise AssertionError(f'option {k!r} has no declared type')
 
 
 def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
@@ -75,7 +89,7 @@ def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
             if k == 'dataset.scale_factor':
                 raise NotImplementedError('dataset.scale_factor (evaluation/data.py:74-77, cv2 resize) is not implemented')
             raise SystemExit(f'unknown option {k!r}; known: {sorted(KNOWN_KEYS)}')
-        cfg[k] = _parse_value(v)
+        cfg[k] = _parse_value(k, v)
     for need in ('model.path', 'indir', 'outdir'):
         if need not in cfg:
             raise SystemExit(f'missing {need}=...')
@@ -191,6 +205,43 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
                                  torch.zeros(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, pin_memory=on_gpu))
         return staging[(Hp, Wp)]
 
+    # the pinned staging buffers are refilled in place every round: the H2D copies of round r must have run before the host writes
+    # round r + 1 into them (only rank 0 synchronises its stream for the D2H; the other ranks would race), and a bucket's plan /
+    # buffers must not be released while the round that uses them is still in flight
+    h2d_done = torch.cuda.Event() if on_gpu else None
+    h2d_pending = False
+
+    side = torch.cuda.Stream(device=device) if on_gpu else None     # gather + D2H of the results, beside the next round's compute
+    prev = None
+
+    def drain(rd, u8, gathered, work, h_out, done):
+        """Rank 0: wait for ONE round's gathered images (not for whatever the compute stream is doing by now), queue the PNG writes."""
+        nonlocal written
+        if on_gpu:
+            with torch.cuda.stream(side):
+                if work is not None:
+                    work.wait()                                 # the side stream waits for RCCL's stream
+                else:
+                    side.wait_event(done)                       # this round's quantize kernel
+                if rank == 0:
+                    h_out.copy_(gathered, non_blocking=True)    # D2H into the pinned result buffer
+            side.synchronize()
+        else:
+            if work is not None:
+                work.wait()
+            if rank == 0:
+                h_out.copy_(gathered)
+        if rank != 0:
+            return
+        host = h_out.numpy()
+        for r, idxs in enumerate(rd['batches']):
+            for j, i in enumerate(idxs):
+                mask_path = items[i][0]
+                h, w = sizes[i]
+                rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + out_ext      # bin/predict.py:69-72
+                futures.append(pool.submit(_write_png, os.path.join(outdir, rel), host[r * batch_size + j, :h, :w].copy()))
+                written += 1
+
     pending = submit_loads(rounds[0]) if rounds else []
     for ri, rd in enumerate(rounds):
         Hp, Wp = rd['shape']
@@ -200,6 +251,9 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
         u8 = torch.zeros(batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
         h_img, h_mask, h_out = staging_of(Hp, Wp)
         if mine:
+            if h2d_pending:
+                h2d_done.synchronize()
+                h2d_pending = False
             img_np, mask_np = h_img.numpy(), h_mask.numpy()
             for j, x in enumerate(loaded):
                 img_np[j], mask_np[j] = x[0], x[1]
@@ -207,30 +261,41 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
             mask_np[len(loaded):] = 0.0
             image = h_img.to(device, non_blocking=True)
             mask = h_mask.to(device, non_blocking=True)
+            if on_gpu:
+                h2d_done.record(torch.cuda.current_stream(image.device))
+                h2d_pending = True
             batch = dict(image=image, mask=(mask > 0) * 1)                          # bin/predict.py:84
             with torch.no_grad():
                 out = model(batch)['inpainted']                                    # bin/predict.py:85, out_key
             stream = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else 0
             lib.quantize_u8_hwc(L.view(out), u8, len(mine), Hp, Wp, stream)        # bin/predict.py:92 on the device
-        if ri + 1 == len(rounds) or rounds[ri + 1]['shape'] != rd['shape']:
-            model.generator.drop_plan((batch_size, 4, Hp, Wp), u8.device)           # bucket done: free its buffers / graph
+        # the only collective: the u8 output images.  Asynchronous, off the compute stream: round r's gather and its D2H run while
+        # round r + 1 is decoded, staged and launched; the host drains round r AFTER it has launched round r + 1
+        work = done = None
+        if on_gpu:
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(u8.device))
         if world > 1:
             gathered = torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
-            dist.all_gather_into_tensor(gathered, u8)                              # the only collective: output images
+            if on_gpu:
+                with torch.cuda.stream(side):
+                    side.wait_event(done)
+                    work = dist.all_gather_into_tensor(gathered, u8, async_op=True)
+            else:
+                work = dist.all_gather_into_tensor(gathered, u8, async_op=True)
         else:
             gathered = u8
-        if rank == 0:
-            h_out.copy_(gathered)               # D2H into the pinned result buffer (synchronises with the stream)
+        last_of_bucket = ri + 1 == len(rounds) or rounds[ri + 1]['shape'] != rd['shape']
+        if prev is not None:
+            drain(*prev)
+        prev = (rd, u8, gathered, work, h_out, done)
+        if last_of_bucket:
+            drain(*prev)
+            prev = None
             if on_gpu:
-                torch.cuda.current_stream(gathered.device).synchronize()
-            host = h_out.numpy()
-            for r, idxs in enumerate(rd['batches']):
-                for j, i in enumerate(idxs):
-                    mask_path = items[i][0]
-                    h, w = sizes[i]
-                    rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + out_ext      # bin/predict.py:69-72
-                    futures.append(pool.submit(_write_png, os.path.join(outdir, rel), host[r * batch_size + j, :h, :w].copy()))
-                    written += 1
+                torch.cuda.current_stream(u8.device).synchronize()                  # every rank: the graph / buffers below are in flight
+                h2d_pending = False
+            model.generator.drop_plan((batch_size, 4, Hp, Wp), u8.device)           # bucket done: free its buffers / graph
     for f in futures:
         f.result()
     pool.shutdown()
@@ -251,7 +316,8 @@ def predict_refine(model, items: List[Tuple[str, str]], indir: str, outdir: str,
         image, mask, (h, w) = load_item(mask_path, img_path, pad_mod)
         batch = dict(image=torch.from_numpy(image)[None].to(device), mask=torch.from_numpy(mask)[None].to(device),
                      unpad_to_size=[torch.tensor([h]), torch.tensor([w])])
-        batch['mask'] = ((batch['mask'] > 0) * 1).float()                                                  # bin/predict.py:84
+        # bin/predict.py:75-81: the refine branch hands the RAW grayscale mask to refine_predict (line 84's binarisation belongs to the
+        # plain branch only); the refiner thresholds it itself at every scale (refinement.py:212,304-305)
         cur_res = refine_predict(batch, model, gpu_ids=str(cfg['refiner.gpu_ids']), modulo=int(cfg['refiner.modulo']),
                                  n_iters=int(cfg['refiner.n_iters']), lr=float(cfg['refiner.lr']), min_side=int(cfg['refiner.min_side']),
                                  max_scales=int(cfg['refiner.max_scales']), px_budget=int(cfg['refiner.px_budget']))

@@ -284,6 +284,7 @@ def refine_predict(batch: dict, inpainter, gpu_ids: str, modulo: int, n_iters: i
             image_inpainted = _infer(image, mb, forward_front, [rear], image_inpainted, orig_shape, [device], ids_, n_iters, lr, trace=tr)
             image_inpainted = image_inpainted[:, :, :orig_shape[0], :orig_shape[1]]
             if trace is not None:
+                tr['out'] = image_inpainted
                 trace.append(tr)
         return image_inpainted
 

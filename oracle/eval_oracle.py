@@ -37,19 +37,3 @@ def ssim_per_image(img1: torch.Tensor, img2: torch.Tensor, window_size: int = 11
     C1, C2 = 0.01 ** 2, 0.03 ** 2
     ssim_map = ((2 * mu1_mu2 + C1) * (2 * sigma12 + C2)) / ((mu1_sq + mu2_sq + C1) * (sigma1_sq + sigma2_sq + C2))
     return ssim_map.mean(1).mean(1).mean(1)
-
-
-def area_bins(masks: np.ndarray, bins: int = 10) -> np.ndarray:
-    """evaluator.py:41-63: bin index of every sample by the share of masked area (area == 1 belongs to the last bin)."""
-    edges = np.linspace(0, 1, bins + 1)
-    area = masks.reshape(masks.shape[0], -1).mean(-1)
-    idx = np.searchsorted(edges, area, side='right') - 1
-    idx[idx == bins] = bins - 1
-    return idx
-
-
-def grouped_mean_std(values: np.ndarray, groups: np.ndarray):
-    """base_loss.py:59-86: ({'mean','std'} overall, {group: {'mean','std'}})."""
-    total = dict(mean=values.mean(), std=values.std())
-    per = {int(gidx): dict(mean=values[groups == gidx].mean(), std=values[groups == gidx].std()) for gidx in np.unique(groups)}
-    return total, per

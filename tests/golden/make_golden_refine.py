@@ -5,6 +5,7 @@ Runs ``oracle.refine_oracle.refine_predict`` (the torch-CPU autograd + Adam rest
 ``saicinpainting/evaluation/refinement.py:86-174,228-314``) on one seeded 1024 x 1024 image, two scales (512 -> 1024),
 ``n_iters=15``, ``lr=0.002`` (the reference defaults, ``configs/prediction/default.yaml`` refiner block) and stores
 
+  * (argv[1] = 1024, default, or 2048 = BASELINE configs[4] itself: 3 scales, px_budget 4194304 as bench.py's refine leg)
   * the per-iteration loss curve of every scale (scale 0 has none: ``ref_lower_res is None`` -> one forward),
   * a strided sample (every 8th pixel) + (mean, std, absmax) of the inpainted image after every scale,
   * a checksum of the seeded synthetic state dict (weights are regenerated from the seed at test time).
@@ -24,10 +25,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-RES, N_ITERS, SEED_SD, SEED_IMG = 1024, 15, 0, 77
+N_ITERS, SEED_SD, SEED_IMG = 15, 0, 77
 
 
-def make_case(res=RES, seed=SEED_IMG):
+def make_case(res, seed=SEED_IMG):
     """One smooth-ish random image and a mask of two rectangles + a thin stroke (holes at several scales)."""
     g = torch.Generator().manual_seed(seed)
     low = torch.rand(1, 3, res // 16, res // 16, generator=g)
@@ -47,17 +48,19 @@ def stat(t):
 
 
 def main():
+    RES = int(sys.argv[1]) if len(sys.argv) > 1 else 1024      # 1024 -> 2 scales (512, 1024); 2048 -> 3 scales = BASELINE configs[4] as bench.py times it
+    MAX_SCALES, PX_BUDGET = (2, 1800000) if RES <= 1024 else (3, 4194304)
     from oracle import lama_oracle as O
     from oracle import refine_oracle as R
     cfg = O.BIG_LAMA
     sd = O.make_synthetic_state_dict(cfg, seed=SEED_SD, calib_hw=64)
-    image, mask = make_case()
+    image, mask = make_case(RES)
     trace = []
     t0 = time.time()
-    out = R.refine_predict(image, mask, (RES, RES), sd, cfg, modulo=8, n_iters=N_ITERS, lr=0.002, min_side=512, max_scales=2,
-                           px_budget=1800000, trace=trace)
+    out = R.refine_predict(image, mask, (RES, RES), sd, cfg, modulo=8, n_iters=N_ITERS, lr=0.002, min_side=512, max_scales=MAX_SCALES,
+                           px_budget=PX_BUDGET, trace=trace)
     print('refine_predict: %.1f s' % (time.time() - t0), flush=True)
-    assert len(trace) == 2 and out.shape == (1, 3, RES, RES)
+    assert len(trace) == MAX_SCALES and out.shape == (1, 3, RES, RES)
     g = dict(res=np.array([RES]), n_iters=np.array([N_ITERS]), seed_sd=np.array([SEED_SD]), seed_img=np.array([SEED_IMG]),
              sd_checksum=np.array([sum(float(v.double().sum()) for v in sd.values() if v.is_floating_point())]))
     for s, tr in enumerate(trace):
@@ -70,8 +73,8 @@ def main():
         plain = O.training_module_forward(dict(image=image, mask=mask), {'generator.' + k: v for k, v in sd.items()}, cfg)['inpainted']
     g['plain_sample'] = plain[:, :, ::8, ::8].numpy()
     g['refine_minus_plain_meanabs'] = np.array([float((out - plain).abs().mean())])
-    np.savez_compressed(os.path.join(HERE, 'refine_biglama_1024.npz'), **g)
-    print('written', os.path.join(HERE, 'refine_biglama_1024.npz'), flush=True)
+    np.savez_compressed(os.path.join(HERE, 'refine_biglama_%d.npz' % RES), **g)
+    print('written', os.path.join(HERE, 'refine_biglama_%d.npz' % RES), flush=True)
 
 
 if __name__ == '__main__':

@@ -99,3 +99,34 @@ def test_predict_world2_gloo_matches_oracle(tmp_path):
         # float parity is <= 1e-3, so after truncation to u8 a level may flip: allow 1 LSB
         assert np.abs(a.astype(int) - u8.astype(int)).max() <= 1, rel
         assert (a != u8).mean() < 0.02
+
+
+def test_bench_spawn_command_for_eight_ranks(monkeypatch):
+    """`python bench.py --gpus 8` re-executes itself under torch.distributed.run: one rank per GPU of ONE node, rendezvous on 127.0.0.1
+    (the container hostname may not resolve), the original flags passed through, dmabuf IPC exported for RCCL."""
+    import bench
+    monkeypatch.delenv('HSA_ENABLE_IPC_MODE_LEGACY', raising=False)
+    argv = ['--gpus', '8', '--steps', '20', '--warmup', '3']
+    cmd, env = bench.spawn_command(8, argv, 29517)
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=8' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[cmd.index('--master-port') + 1] == '29517'
+    script = cmd.index(os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == argv and script > cmd.index('--master-port')
+    assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', '1')          # an explicit choice of the caller is kept
+    assert bench.spawn_command(2, [], 1)[1]['HSA_ENABLE_IPC_MODE_LEGACY'] == '1'
+
+
+def test_predict_overrides_are_typed_per_key():
+    """Paths / names stay strings whatever they look like; numeric options are numbers; junk is rejected."""
+    cfg = P.parse_overrides(['model.path=/m', 'indir=2024', 'outdir=7', 'model.checkpoint=100', 'batch_size=4', 'refine=True',
+                             'refiner.lr=0.01', 'refiner.gpu_ids=0,1', 'refiner.n_iters=5', 'dataset.img_suffix=.jpg'])
+    assert cfg['indir'] == '2024' and cfg['outdir'] == '7' and cfg['model.checkpoint'] == '100' and cfg['dataset.img_suffix'] == '.jpg'
+    assert cfg['batch_size'] == 4 and cfg['refine'] is True and cfg['refiner.lr'] == 0.01 and cfg['refiner.gpu_ids'] == '0,1'
+    assert cfg['refiner.n_iters'] == 5 and cfg['refiner.px_budget'] == 1800000
+    assert (cfg['indir'] + os.sep).endswith(os.sep) and os.path.join(cfg['model.path'], 'models', cfg['model.checkpoint']) == '/m/models/100'
+    for bad in ('batch_size=four', 'refine=maybe', 'refiner.lr=fast'):
+        with pytest.raises(SystemExit):
+            P.parse_overrides(['model.path=/m', 'indir=i', 'outdir=o', bad])
+    assert set(P.KNOWN_KEYS) == P.STRING_KEYS | P.BOOL_KEYS | P.INT_KEYS | P.FLOAT_KEYS

@@ -47,6 +47,26 @@ def test_pyramid_helpers_match_reference_semantics(setup):
             assert a.shape == b.shape and torch.allclose(a, b, atol=1e-6)
 
 
+def test_grayscale_mask_gives_the_pyramid_of_the_reference(setup):
+    """bin/predict.py:75-81 hands the RAW grayscale mask (PNG levels / 255) to refine_predict -- line 84's binarisation belongs to
+    the plain branch.  The pyramid of a gray mask must equal the oracle's on the same gray mask at every scale AFTER the scale loop's
+    own threshold (refinement.py:304-305), without and with the px_budget resize."""
+    g = torch.Generator().manual_seed(9)
+    gray = torch.zeros(1, 1, 72, 96)
+    gray[:, :, 12:50, 20:70] = 1.0
+    gray[:, :, 10:12, 20:70] = 128 / 255.0                 # anti-aliased rim of a drawn mask
+    gray[:, :, 30:40, 70:72] = 3 / 255.0
+    batch = dict(image=torch.rand(1, 3, 72, 96, generator=g), mask=gray, unpad_to_size=[torch.tensor([70]), torch.tensor([93])])
+    for budget in (100000, 3000):
+        ims, mks = RF._get_image_mask_pyramid(batch, min_side=20, max_scales=3, px_budget=budget)
+        rims, rmks = R.get_image_mask_pyramid(batch['image'], gray, (70, 93), 20, 3, budget)
+        for a, b in zip(mks, rmks):
+            assert a.shape == b.shape and torch.allclose(a, b, atol=1e-6)
+            assert torch.equal((a >= 1e-8), (b >= 1e-8))
+        for a, b in zip(ims, rims):
+            assert torch.allclose(a, b, atol=1e-6)
+
+
 def test_infer_one_scale_matches_autograd_adam(setup):
     """_infer on one scale with a lower-resolution reference: the losses of every iteration, the first gradient and the final
     inpainting against torch autograd + torch.optim.Adam through the oracle (refinement.py:86-174)."""

@@ -1,5 +1,7 @@
 """GPU parity of the refinement path (BASELINE configs[4], saicinpainting/evaluation/refinement.py) against the CPU oracle:
 gradients of the explicit reverse pass at big-lama's channel counts against torch autograd, and refine_predict end to end."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -87,3 +89,58 @@ def test_refine_predict_end_to_end():
     assert out.shape == ref.shape == (1, 3, Hh, Ww) and len(trace) == 2 and len(trace[1]['loss']) == 5
     assert float((out - ref).abs().max()) < 1e-2 and float((out - ref).abs().mean()) < 3e-4
     assert trace[1]['loss'][-1] < trace[1]['loss'][0]           # the refinement does reduce its loss
+
+
+@pytest.fixture(scope='module')
+def biglama_module():
+    """The FULL big-lama generator (18 FFCResnetBlocks) with the seeded synthetic weights of the goldens (seed 0, calib 64)."""
+    cfg = dict(O.BIG_LAMA)
+    sd = O.make_synthetic_state_dict(cfg, seed=0, calib_hw=64)
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
+    model.load_state_dict({'generator.' + k: v for k, v in sd.items()}, strict=True)
+    model.freeze().cuda()
+    checksum = sum(float(v.double().sum()) for v in sd.values() if v.is_floating_point())
+    return model, checksum
+
+
+@pytest.mark.parametrize('res', [1024, 2048], ids=['2scales_512_1024', 'configs4_3scales_2048'])
+def test_refine_predict_biglama_golden(biglama_module, golden_dir, res):
+    """BASELINE configs[4] at its own configuration: ``refine_predict`` on the full big-lama generator, 15 iterations per scale
+    (res = 2048: exactly what bench.py's ``configs4_refine_leg`` times -- 3 scales 512 / 1024 / 2048, px_budget 4194304), against
+    the loss curves and output samples that ``tests/golden/make_golden_refine.py`` recorded from the CPU oracle (torch autograd +
+    torch.optim.Adam through all 18 blocks).  Bars: every loss within 1 % of the oracle's and monotonically falling; the refined
+    image within 3e-4 mean-abs / 5e-3 max-abs of the oracle's on the stored sample (every 8th pixel), and clearly different from
+    the un-refined forward (so "did nothing" cannot pass)."""
+    path = os.path.join(golden_dir, f'refine_biglama_{res}.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{path} not generated')
+    g = np.load(path)
+    model, checksum = biglama_module
+    assert abs(checksum - float(g['sd_checksum'][0])) < 1e-3 * abs(checksum), 'seeded weights drifted from the golden run'
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_refine', os.path.join(golden_dir, 'make_golden_refine.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    image, mask = mk.make_case(res=res, seed=int(g['seed_img'][0]))
+    n_scales, px_budget = (2, 1800000) if res <= 1024 else (3, 4194304)
+    batch = dict(image=image.cuda(), mask=mask.cuda(), unpad_to_size=[torch.tensor([res]), torch.tensor([res])])
+    trace = []
+    out = RF.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=int(g['n_iters'][0]), lr=0.002, min_side=512,
+                            max_scales=n_scales, px_budget=px_budget, trace=trace)
+    assert out.shape == (1, 3, res, res) and len(trace) == n_scales
+    report = []
+    for s in range(n_scales):
+        ref_loss = g[f'loss{s}']
+        got = np.asarray(trace[s].get('loss', []), dtype=np.float64)
+        assert got.shape == ref_loss.shape
+        if len(ref_loss):
+            rel = np.abs(got - ref_loss) / ref_loss
+            report.append(f'scale {s}: max loss rel err {rel.max():.2e}')
+            assert rel.max() < 1e-2, (s, got, ref_loss)
+            assert np.all(np.diff(got) < 0)
+        d = (trace[s]['out'][:, :, ::8, ::8].numpy() - g[f'out{s}_sample'])
+        report.append(f'scale {s}: out mean-abs {np.abs(d).mean():.2e} max-abs {np.abs(d).max():.2e}')
+        assert np.abs(d).mean() < 3e-4 and np.abs(d).max() < 5e-3, report
+    moved = float(np.abs(out[:, :, ::8, ::8].numpy() - g['plain_sample']).mean())
+    assert moved > 0.3 * float(g['refine_minus_plain_meanabs'][0]), (moved, g['refine_minus_plain_meanabs'])
+    print('\n'.join(report))

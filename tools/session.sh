@@ -1,0 +1,75 @@
+#!/bin/bash
+# ONE GPU-box session script (replaces the 38 one-off tools/gpu_session_r02*.sh of round 2; those are in the git history).
+# Run through gpurun from the repo root:   gpurun --timeout 900 -- 'bash tools/session.sh <tag> <step> [<step> ...]'
+# Results go to gpurun_out/<tag>/ (summary.txt collects one-line results); copy what is to be judged into profiles/.
+#
+# steps (run in the order given):
+#   tests[:<pytest -k expr>]   pytest -m gpu (optionally -k expr)                          -> pytest_gpu.log
+#   smoke                      __graft_entry__.smoke()
+#   bench[:<extra flags>]      python bench.py <flags>                                     -> bench.json (+ one-line digest)
+#   quick                      bench without the cpu / f32 / eager / configs legs          -> bench_quick.json
+#   stats                      rocprofv3 --kernel-trace --stats of the quick bench         -> kernel_stats.csv, timeline.txt
+#   pmc:<kprobe names>         rocprofv3 --pmc passes (one counter set per run) over tools/kprobe.py f16x3 <names>  -> pmc_<names>/
+#   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline) -> pmc_bench/
+#   shapes                     the other single-GPU shapes (4x1024, 4x256, 1x512, 1x2048)
+#   kbench                     per-kernel timings, operands rotated out of the Infinity Cache (KBENCH_ROT=6)
+#   power                      MFMA sustained-rate micro-benchmark (tools/ubench/mfma_power.hip)
+#   ab:<ENV>=<v1>,<v2>[,...]   same-box A/B of an environment switch of the PROFILING library, two rounds   -> ab_<ENV>.txt
+#   ablib:<path/base.so>       same-box A/B of another build of the library against the in-tree one (LAMA_HIP_LIB)
+#   py:<script> [args]         python <script> args  (quote the step)                      -> py_<script>.log
+TAG=${1:?usage: session.sh <tag> <step>...}; shift
+O=gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+QUICK="--steps 20 --warmup 3 --no-cpu-baseline --no-f32-leg --no-eager-leg"
+digest() { python - "$1" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r, f = d.get('roofline') or {}, d.get('roofline_ffc') or {}
+print('bench:', d['value'], d['unit'], d['ms_per_step'], 'ms | roofline', r.get('kernel'), r.get('achieved'), 'TF frac', r.get('frac'),
+      '| ffc', f.get('avg_us'), 'us frac', f.get('frac'), 'traffic', f.get('traffic'))
+for k in ('pytorch_rocm_eager', 'exact_f32_leg', 'cpu_baseline', 'configs2_fp16_leg', 'configs4_refine_leg', 'value_with_h2d_d2h'):
+    if d.get(k):
+        print(' ', k, json.dumps(d[k])[:220])
+print('  kernels_us:', json.dumps(d.get('kernels_us'))[:1200])
+PY
+}
+for STEP in "$@"; do
+  KIND=${STEP%%:*}; ARG=""; [ "$KIND" != "$STEP" ] && ARG=${STEP#*:}
+  echo "== $STEP" | tee -a $O/summary.txt
+  case $KIND in
+    tests)  if [ -n "$ARG" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$ARG" > $O/pytest_gpu.log 2>&1; else timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; fi
+            tail -5 $O/pytest_gpu.log | tee -a $O/summary.txt ;;
+    smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/summary.txt ;;
+    bench)  timeout 1200 python bench.py $ARG > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; digest $O/bench.json | tee -a $O/summary.txt ;;
+    quick)  timeout 400 python bench.py $QUICK > $O/bench_quick.json 2> $O/bench_quick.err; tail -c 300 $O/bench_quick.err; digest $O/bench_quick.json | tee -a $O/summary.txt ;;
+    stats)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
+            for db in $(find $O/prof -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats.csv; python tools/timeline.py $db $O/timeline.txt 4; done
+            rm -rf $O/prof; head -16 $O/kernel_stats.csv | cut -c1-170 | tee -a $O/summary.txt ;;
+    pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
+    pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
+              (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
+              f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f | tee $O/pmc_bench_$CNT.txt | head -40 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done ;;
+    shapes) for cfg in "4 1024" "4 256" "1 512" "1 2048"; do set -- $cfg
+              LAMA_BENCH_BATCH=$1 LAMA_BENCH_RES=$2 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('$1 x $2:', d['value'], 'images/s', d['ms_per_step'], 'ms')" | tee -a $O/summary.txt; done ;;
+    kbench) KBENCH_ROT=6 timeout 300 python tools/kbench.py f16x3 all cold > $O/kbench_cold.log 2>&1; cp gpurun_out/kbench_cold.json $O/ 2>/dev/null; tail -30 $O/kbench_cold.log | tee -a $O/summary.txt ;;
+    power)  hipcc --offload-arch=gfx950 -O3 -w tools/ubench/mfma_power.hip -o /tmp/mfma_power && /tmp/mfma_power 2>&1 | tee $O/mfma_power.txt | tail -12 | tee -a $O/summary.txt ;;
+    ab)     ENVN=${ARG%%=*}; VALS=$(echo ${ARG#*=} | tr ',' ' ')
+            for i in 1 2; do for v in $VALS; do
+              echo -n "$ENVN=$v: " | tee -a $O/ab_$ENVN.txt
+              env LAMA_HIP_LIB=$PWD/lama_amd/lib/liblama_hip_prof.so $ENVN=$v timeout 300 python bench.py $QUICK 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms', 'ffc', (d.get('roofline_ffc') or {}).get('avg_us'))" | tee -a $O/ab_$ENVN.txt; done; done
+            cat $O/ab_$ENVN.txt >> $O/summary.txt ;;
+    ablib)  for i in 1 2; do for v in base new; do
+              if [ $v = base ]; then export LAMA_HIP_LIB=$PWD/$ARG; else unset LAMA_HIP_LIB; fi
+              echo "$v: $(timeout 300 python bench.py $QUICK 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')" | tee -a $O/ablib.txt; done; done; unset LAMA_HIP_LIB
+            cat $O/ablib.txt >> $O/summary.txt ;;
+    py)     set -- $ARG; timeout 900 python "$@" > $O/py_$(basename $1 .py).log 2>&1; tail -40 $O/py_$(basename $1 .py).log | tee -a $O/summary.txt ;;
+    *)      echo "unknown step $STEP" | tee -a $O/summary.txt ;;
+  esac
+done
+echo "== done" | tee -a $O/summary.txt
