@@ -189,6 +189,9 @@ def _infer(image: torch.Tensor, mask: torch.Tensor, forward_front, forward_rears
             if trace is not None and idi == 0:
                 trace['pred0'], trace['g_z'] = pred.clone(), g_z.clone()
             lib.adam_step(z, g_z, m_adam, v_adam, lr, idi + 1, stream=st)                 # refinement.py:165 optimizer.step()
+            if trace is not None and trace.get('keep_z'):
+                trace.setdefault('z', []).append(z.clone())
+                trace.setdefault('g', []).append(g_z.clone())
     inpainted = torch.empty(B, 3, H, W, device=image.device)
     lib.blend(L.view(image), L.view(mask), L.view(pred), L.view(inpainted), B, st)        # refinement.py:171
     return inpainted.detach().cpu()
@@ -244,9 +247,10 @@ def _pad_tensor_to_modulo(img: torch.Tensor, mod: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------------------------
 
 def refine_predict(batch: dict, inpainter, gpu_ids: str, modulo: int, n_iters: int, lr: float, min_side: int, max_scales: int,
-                   px_budget: int, trace: Optional[list] = None):
+                   px_budget: int, trace: Optional[list] = None, bwd_precision: Optional[int] = None):
     """refinement.py:228-314: coarse-to-fine refinement of the features after generator.model[:first_resblock].
-    Returns the inpainted image [1, 3, H, W] (CPU tensor, like the reference)."""
+    Returns the inpainted image [1, 3, H, W] (CPU tensor, like the reference).  ``bwd_precision`` (extension): precision of the
+    explicit reverse pass, default the 3-term bf16 split (L.PREC_F32 = exact fp32 MFMA, ~5x slower)."""
     assert not inpainter.training
     assert not getattr(inpainter, 'add_noise_kwargs', None)
     assert inpainter.concat_mask
@@ -289,7 +293,7 @@ def refine_predict(batch: dict, inpainter, gpu_ids: str, modulo: int, n_iters: i
         return image_inpainted
 
     try:
-        return run(RearPass(gen, first_resblock_ind))
+        return run(RearPass(gen, first_resblock_ind) if bwd_precision is None else RearPass(gen, first_resblock_ind, bwd_precision=bwd_precision))
     except LamaRangeError as e:
         if not getattr(gen, 'auto_fallback', True) or gen.precision != L.PREC_F16X3:
             raise

@@ -143,15 +143,20 @@ def first_resblock_index(cfg: dict) -> int:
 
 
 def infer(image: Tensor, mask: Tensor, sd: Dict[str, Tensor], cfg: dict, ref_lower_res: Optional[Tensor], orig_shape,
-          n_iters: int = 15, lr: float = 0.002, prefix: str = 'model.', trace: Optional[dict] = None) -> Tensor:
+          n_iters: int = 15, lr: float = 0.002, prefix: str = 'model.', trace: Optional[dict] = None, z_noise: float = 0.0) -> Tensor:
     """refinement.py:86-174 on one device.  ``trace`` (optional) receives per-iteration losses and the first-iteration
-    gradients of (z1, z2) for the gradient-parity tests."""
+    gradients of (z1, z2) for the gradient-parity tests.  ``z_noise`` (sensitivity experiments only): relative gaussian perturbation of
+    the initial features, e.g. 2e-6 ~ the rounding difference between two valid fp32 evaluations of the front layers."""
     fri = first_resblock_index(cfg)
     masked_image = torch.cat([image * (1 - mask), mask], dim=1)
     mask3 = mask.repeat(1, 3, 1, 1)
     with torch.no_grad():
         z1, z2 = O.run_layers(masked_image, sd, cfg, 0, fri, prefix)
     ekernel = ellipse_kernel(15)
+    if z_noise:
+        gn = torch.Generator().manual_seed(991)
+        z1 = z1 * (1.0 + z_noise * torch.randn(z1.shape, generator=gn))
+        z2 = z2 * (1.0 + z_noise * torch.randn(z2.shape, generator=gn))
     z1, z2 = z1.detach().clone().requires_grad_(True), z2.detach().clone().requires_grad_(True)
     opt = torch.optim.Adam([z1, z2], lr=lr)
     pred = None
@@ -172,6 +177,9 @@ def infer(image: Tensor, mask: Tensor, sd: Dict[str, Tensor], cfg: dict, ref_low
                 trace['g_z1'], trace['g_z2'] = z1.grad.clone(), z2.grad.clone()
                 trace['pred0'] = pred.detach().clone()
             opt.step()
+            if trace is not None and trace.get('keep_z'):
+                trace.setdefault('z', []).append(torch.cat([z1.detach(), z2.detach()], 1).clone())
+                trace.setdefault('g', []).append(torch.cat([z1.grad, z2.grad], 1).clone())
     return (mask3 * pred + (1 - mask3) * image).detach()
 
 
@@ -201,7 +209,7 @@ def get_image_mask_pyramid(image: Tensor, mask: Tensor, unpad_to_size, min_side:
 
 def refine_predict(image: Tensor, mask: Tensor, unpad_to_size, sd, cfg: dict, modulo: int = 8, n_iters: int = 15, lr: float = 0.002,
                    min_side: int = 512, max_scales: int = 3, px_budget: int = 1800000, prefix: str = 'model.',
-                   trace: Optional[list] = None) -> Tensor:
+                   trace: Optional[list] = None, z_noise: float = 0.0) -> Tensor:
     """refinement.py:228-314 on one device: image [1,3,H,W], mask [1,1,H,W] -> inpainted [1,3,h,w].  ``trace`` (optional list)
     receives one dict per scale: the per-iteration losses of ``infer`` and the scale's inpainted image."""
     ls_images, ls_masks = get_image_mask_pyramid(image, mask, unpad_to_size, min_side, max_scales, px_budget)
@@ -212,7 +220,7 @@ def refine_predict(image: Tensor, mask: Tensor, unpad_to_size, sd, cfg: dict, mo
         msk = pad_tensor_to_modulo(msk, modulo)
         msk = (msk >= 1e-8).to(msk.dtype)
         tr = {} if trace is not None else None
-        image_inpainted = infer(img, msk, sd, cfg, image_inpainted, orig_shape, n_iters, lr, prefix, trace=tr)
+        image_inpainted = infer(img, msk, sd, cfg, image_inpainted, orig_shape, n_iters, lr, prefix, trace=tr, z_noise=z_noise)
         image_inpainted = image_inpainted[:, :, :orig_shape[0], :orig_shape[1]]
         if trace is not None:
             tr['out'] = image_inpainted

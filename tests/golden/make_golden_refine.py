@@ -47,9 +47,43 @@ def stat(t):
     return np.array([t.mean().item(), t.std().item(), t.abs().max().item()])
 
 
+def self_sensitivity(RES, MAX_SCALES, PX_BUDGET, z_noise=2e-6):
+    """How far apart are two VALID fp32 evaluations of this very algorithm?  The refinement loss is an L1 (its gradient is sign(pred - image):
+    a 1e-5 difference in the prediction flips the sign for ~0.1 % of the pixels) and Adam normalises the gradient (an element whose gradient
+    changes sign moves the other way by the full learning rate), so the 15-iteration trajectory is chaotic in the rounding of the forward
+    pass.  Measured here by running the ORACLE a second time with the initial features perturbed by a relative 2e-6 (one or two fp32 ulps,
+    what a different summation order of the front layers produces) and comparing with the stored golden run: per scale the mean / max
+    absolute difference of the inpainted sample and the largest relative difference of the loss curve.  A HIP run cannot be expected to be
+    closer to the golden than the oracle is to itself; tests/test_refinement_gpu.py bounds it by a small multiple of these numbers."""
+    from oracle import lama_oracle as O
+    from oracle import refine_oracle as R
+    path = os.path.join(HERE, 'refine_biglama_%d.npz' % RES)
+    g = dict(np.load(path))
+    cfg = O.BIG_LAMA
+    sd = O.make_synthetic_state_dict(cfg, seed=SEED_SD, calib_hw=64)
+    image, mask = make_case(RES)
+    trace = []
+    t0 = time.time()
+    R.refine_predict(image, mask, (RES, RES), sd, cfg, modulo=8, n_iters=N_ITERS, lr=0.002, min_side=512, max_scales=MAX_SCALES,
+                     px_budget=PX_BUDGET, trace=trace, z_noise=z_noise)
+    print('perturbed refine_predict: %.1f s' % (time.time() - t0), flush=True)
+    for s, tr in enumerate(trace):
+        ref = g[f'out{s}_sample']
+        st = tr['out'].shape[-1] // ref.shape[-1]
+        d = np.abs(tr['out'][:, :, ::st, ::st].numpy() - ref)
+        loss = np.array(tr.get('loss', []), dtype=np.float64)
+        rel = float(np.max(np.abs(loss - g[f'loss{s}']) / g[f'loss{s}'])) if len(loss) else 0.0
+        g[f'self{s}'] = np.array([d.mean(), d.max(), rel])
+        print(f'scale {s}: oracle vs perturbed oracle: out mean-abs {d.mean():.3e} max-abs {d.max():.3e}, loss rel {rel:.3e}', flush=True)
+    g['self_z_noise'] = np.array([z_noise])
+    np.savez_compressed(path, **g)
+
+
 def main():
     RES = int(sys.argv[1]) if len(sys.argv) > 1 else 1024      # 1024 -> 2 scales (512, 1024); 2048 -> 3 scales = BASELINE configs[4] as bench.py times it
     MAX_SCALES, PX_BUDGET = (2, 1800000) if RES <= 1024 else (3, 4194304)
+    if len(sys.argv) > 2 and sys.argv[2] == 'self':            # second pass: the algorithm's own sensitivity, added to the existing file
+        return self_sensitivity(RES, MAX_SCALES, PX_BUDGET)
     from oracle import lama_oracle as O
     from oracle import refine_oracle as R
     cfg = O.BIG_LAMA
@@ -65,13 +99,16 @@ def main():
              sd_checksum=np.array([sum(float(v.double().sum()) for v in sd.values() if v.is_floating_point())]))
     for s, tr in enumerate(trace):
         g[f'loss{s}'] = np.array(tr.get('loss', []), dtype=np.float64)
-        g[f'out{s}_sample'] = tr['out'][:, :, ::8, ::8].numpy()
+        st = max(8, tr['out'].shape[-1] // 128)              # <= 128 x 128 samples per scale
+        g[f'out{s}_sample'] = tr['out'][:, :, ::st, ::st].numpy()
+        g[f'out{s}_stride'] = np.array([st])
         g[f'out{s}_stat'] = stat(tr['out'])
         print('scale', s, 'losses', g[f'loss{s}'], flush=True)
     # what refinement changed vs the plain forward at full resolution (so the test can tell "refined" from "not refined")
     with torch.no_grad():
         plain = O.training_module_forward(dict(image=image, mask=mask), {'generator.' + k: v for k, v in sd.items()}, cfg)['inpainted']
-    g['plain_sample'] = plain[:, :, ::8, ::8].numpy()
+    g['sample_stride'] = np.array([max(8, RES // 128)])
+    g['plain_sample'] = plain[:, :, ::max(8, RES // 128), ::max(8, RES // 128)].numpy()
     g['refine_minus_plain_meanabs'] = np.array([float((out - plain).abs().mean())])
     np.savez_compressed(os.path.join(HERE, 'refine_biglama_%d.npz' % RES), **g)
     print('written', os.path.join(HERE, 'refine_biglama_%d.npz' % RES), flush=True)

@@ -72,6 +72,15 @@ CONV_CASES = [
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True),
     dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False),
     dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True),      # rows past M in the last fragment
+    # ... the same three on the round-2 weights-in-registers kernel (LAMA_GEMM_WL=0), and the weights-in-LDS kernel with ONE workgroup per row
+    # group (LAMA_GEMM_WL_SLOTS=1: 8 waves) so that a few tiles make whole rounds + (tile, fragment) thirds / an extra whole tile
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True, wl=0),
+    dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False, wl=0),
+    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True, wl=0),
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True, wl_slots=1),      # 8 tiles on 8 waves: one whole round
+    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True, wl_slots=1),   # 18 tiles: two rounds + 6 thirds
+    dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=True, scale=False, wl_slots=1),   # 10 tiles: one round + 6 thirds, residual
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=31, act=1, bias=True, resid=False, scale=True, wl_slots=1),     # 14 tiles: one round + 6 whole left-overs
     # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
     dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True),
     dict(cin=3, cout=40, k=7, stride=1, pad=3, H=6, W=20, act=0, bias=False, resid=False, scale=False),
@@ -88,9 +97,13 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}")
 def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
+    if 'wl' in case:
+        monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
+    if 'wl_slots' in case:
+        monkeypatch.setenv('LAMA_GEMM_WL_SLOTS', str(case['wl_slots']))
     if case.get('geo'):
         monkeypatch.setenv('LAMA_CW_41', str(case['geo']))
     if 'cwt' in case:

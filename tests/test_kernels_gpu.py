@@ -42,9 +42,13 @@ DEV = 'cuda'
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}")
 def test_conv2d(anylib, case, prec, monkeypatch):
     lib = anylib
+    if 'wl' in case:        # pointwise GEMM: the round-2 weights-in-registers kernel (profiling build switch)
+        monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
+    if 'wl_slots' in case:
+        monkeypatch.setenv('LAMA_GEMM_WL_SLOTS', str(case['wl_slots']))
     if 'cwt' in case:       # ConvTranspose2d as four parity-class launches: a switch of the profiling build (the product keeps the fused launch)
         monkeypatch.setenv('LAMA_CWT', str(case['cwt']))
     g = torch.Generator().manual_seed(1)

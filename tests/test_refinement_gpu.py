@@ -103,14 +103,25 @@ def biglama_module():
     return model, checksum
 
 
+@pytest.mark.parametrize('precs', [(L.PREC_F16X3, None), (L.PREC_F32, L.PREC_F32)], ids=['default_f16x3_fwd_bf16x3_bwd', 'exact_f32'])
 @pytest.mark.parametrize('res', [1024, 2048], ids=['2scales_512_1024', 'configs4_3scales_2048'])
-def test_refine_predict_biglama_golden(biglama_module, golden_dir, res):
+def test_refine_predict_biglama_golden(biglama_module, golden_dir, res, precs):
     """BASELINE configs[4] at its own configuration: ``refine_predict`` on the full big-lama generator, 15 iterations per scale
     (res = 2048: exactly what bench.py's ``configs4_refine_leg`` times -- 3 scales 512 / 1024 / 2048, px_budget 4194304), against
     the loss curves and output samples that ``tests/golden/make_golden_refine.py`` recorded from the CPU oracle (torch autograd +
-    torch.optim.Adam through all 18 blocks).  Bars: every loss within 1 % of the oracle's and monotonically falling; the refined
-    image within 3e-4 mean-abs / 5e-3 max-abs of the oracle's on the stored sample (every 8th pixel), and clearly different from
-    the un-refined forward (so "did nothing" cannot pass)."""
+    torch.optim.Adam through all 18 blocks), in the default precision (f16x3 forward, bf16x3 reverse pass) and in exact fp32.
+
+    What can be asked of the OUTPUT.  The refinement loss is an L1: its gradient is sign(pred - image), so a 1e-5 difference in the
+    prediction flips the sign for ~0.1 % of the pixels (measured on the GPU box, tools/refine_diag.py: first-iteration gradient of the
+    EXACT-fp32 reverse pass 1.1e-2 relative L2 from autograd's with pred0 4e-5 apart), and Adam turns a sign change of a gradient element
+    into a full learning-rate step the other way: the 15-iteration trajectory is chaotic in the rounding of the forward pass.  The
+    golden file therefore carries the algorithm's OWN sensitivity: the oracle re-run with the initial features perturbed by a relative
+    2e-6 (two valid fp32 evaluations of the front layers differ by that much) lands 1.14e-3 mean-abs / 3.3e-2 max-abs from the golden
+    output at the 1024 scale while its loss curve stays within 9e-6 -- and the HIP path lands 1.15e-3 / 3.3e-2 / 1.1e-5 from it, in
+    exact fp32 and in the default precision alike (profiles/r03_refine_parity.txt).  Bars: every loss within 1e-4 of the oracle's
+    (10x the self-sensitivity) and monotonically falling; the refined image within 2x the oracle's self-distance (mean and max; floors
+    3e-4 / 5e-3, which the first scale -- a plain forward -- meets by three orders of magnitude); and clearly different from the
+    un-refined forward (so "did nothing" cannot pass)."""
     path = os.path.join(golden_dir, f'refine_biglama_{res}.npz')
     if not os.path.exists(path):
         pytest.skip(f'{path} not generated')
@@ -125,8 +136,12 @@ def test_refine_predict_biglama_golden(biglama_module, golden_dir, res):
     n_scales, px_budget = (2, 1800000) if res <= 1024 else (3, 4194304)
     batch = dict(image=image.cuda(), mask=mask.cuda(), unpad_to_size=[torch.tensor([res]), torch.tensor([res])])
     trace = []
-    out = RF.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=int(g['n_iters'][0]), lr=0.002, min_side=512,
-                            max_scales=n_scales, px_budget=px_budget, trace=trace)
+    model.generator.set_precision(precs[0])
+    try:
+        out = RF.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=int(g['n_iters'][0]), lr=0.002, min_side=512,
+                                max_scales=n_scales, px_budget=px_budget, trace=trace, bwd_precision=precs[1])
+    finally:
+        model.generator.set_precision(L.PREC_F16X3)
     assert out.shape == (1, 3, res, res) and len(trace) == n_scales
     report = []
     for s in range(n_scales):
@@ -136,11 +151,17 @@ def test_refine_predict_biglama_golden(biglama_module, golden_dir, res):
         if len(ref_loss):
             rel = np.abs(got - ref_loss) / ref_loss
             report.append(f'scale {s}: max loss rel err {rel.max():.2e}')
-            assert rel.max() < 1e-2, (s, got, ref_loss)
+            assert rel.max() < 1e-4, (s, got, ref_loss)
             assert np.all(np.diff(got) < 0)
-        d = (trace[s]['out'][:, :, ::8, ::8].numpy() - g[f'out{s}_sample'])
+        o = trace[s]['out']
+        st = o.shape[-1] // g[f'out{s}_sample'].shape[-1]
+        d = (o[:, :, ::st, ::st].numpy() - g[f'out{s}_sample'])
         report.append(f'scale {s}: out mean-abs {np.abs(d).mean():.2e} max-abs {np.abs(d).max():.2e}')
-        assert np.abs(d).mean() < 3e-4 and np.abs(d).max() < 5e-3, report
-    moved = float(np.abs(out[:, :, ::8, ::8].numpy() - g['plain_sample']).mean())
+        self_mean, self_max = (float(g[f'self{s}'][0]), float(g[f'self{s}'][1])) if f'self{s}' in g.files else (0.0, 0.0)
+        report.append(f'         (oracle vs perturbed oracle: mean-abs {self_mean:.2e} max-abs {self_max:.2e})')
+        print('\n'.join(report[-2:]), flush=True)
+        assert np.abs(d).mean() < max(3e-4, 2 * self_mean) and np.abs(d).max() < max(5e-3, 2 * self_max), report
+    st = int(g['sample_stride'][0])
+    moved = float(np.abs(out[:, :, ::st, ::st].numpy() - g['plain_sample']).mean())
     assert moved > 0.3 * float(g['refine_minus_plain_meanabs'][0]), (moved, g['refine_minus_plain_meanabs'])
     print('\n'.join(report))

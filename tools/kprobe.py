@@ -49,6 +49,22 @@ def main():
                                   L.ACT_RELU, None if resid is None else L.view(resid), None if x2 is None else L.view(x2), w2p, precision=prec,
                                   stream=st, fuse1=None if f1 is None else f1[:3], cooperative=coop)
 
+    def fu_rot():
+        # FourierUnit.forward (ffc.py:76-113) as lama_fourier_unit_fwd, KPROBE_ROT operand sets used round-robin so that a call does
+        # not find its operands of the previous call in the 256 MiB Infinity Cache (default 6 sets x ~130 MB)
+        nrot = int(os.environ.get('KPROBE_ROT', '6'))
+        wp = lib.pack_conv_weight(rnd(384, 384, 1, 1) * 0.05, None, precision=prec)
+        bias = rnd(384)
+        sets = [(rnd(B, 192, h, w), torch.empty(B, 192, h, w, device=dev),
+                 torch.empty(lib.fourier_unit_workspace_bytes(B, 192, h, w), dtype=torch.uint8, device=dev)) for _ in range(nrot)]
+        k = [0]
+
+        def run():
+            x, yy, ws = sets[k[0] % nrot]
+            k[0] += 1
+            lib.fourier_unit(L.view(x), wp, bias, L.view(yy), B, True, ws, precision=prec, stream=st)
+        return run
+
     x1 = rnd(B, 192, h, w)
     spec = torch.empty(B, 384, h, w // 2 + 1, device=dev)
     y = torch.empty_like(x1)
@@ -69,6 +85,7 @@ def main():
         'up3': lambda: conv(128, 64, 3, 256, 256, tr=True),
         'stem': lambda: conv(4, 64, 7, 512, 512),
         'head': lambda: conv(64, 3, 7, 512, 512),
+        'fu': lambda: fu_rot(),
         'rfft': lambda: (lambda: lib.rfft2(L.view(x1), L.view(spec), B, None, st)),
         'irfft': lambda: (lambda: lib.irfft2(L.view(spec), L.view(x1), L.view(y), B, None, st)),
     }
