@@ -112,8 +112,8 @@ class KernelTimer:
     def __init__(self, lib):
         self.lib, self.records, self.on = lib, {}, False
         self.flops, self.bytes = {}, {}
-        self._conv, self._fu = lib.conv2d, lib.fourier_unit
-        lib.conv2d, lib.fourier_unit = self.conv2d, self.fourier_unit
+        self._conv, self._fu, self._wino = lib.conv2d, lib.fourier_unit, lib.winograd_conv3x3
+        lib.conv2d, lib.fourier_unit, lib.winograd_conv3x3 = self.conv2d, self.fourier_unit, self.winograd_conv3x3
 
     def _timed(self, key, fn, *a, **kw):
         if not self.on:
@@ -142,6 +142,16 @@ class KernelTimer:
 
     def fourier_unit(self, x, *a, **kw):
         return self._timed(f'fourier_unit_c{x.C}_{x.H}x{x.W}', self._fu, x, *a, **kw)
+
+    def winograd_conv3x3(self, x, w_packed, y, batch, *a, **kw):
+        # the SAME function as the direct 3x3 launch (same key, so every consumer of the table finds the layer); the algorithmic FLOPs are
+        # those of the direct convolution: what Winograd removes is MFMA products, not work the layer specifies.  Two launches (GEMM in
+        # the transform domain + inverse transform / epilogue), timed together.
+        key = f'conv3x3_cin{x.C}_cout{y.C}_{y.H}x{y.W}'
+        self.flops[key] = 2.0 * batch * y.H * y.W * y.C * x.C * 9
+        self.bytes[key] = 4.0 * batch * (x.C * x.H * x.W + y.C * y.H * y.W)
+        self.winograd_keys = getattr(self, 'winograd_keys', set()) | {key}
+        return self._timed(key, self._wino, x, w_packed, y, batch, *a, **kw)
 
     def summary(self):
         out = {}
@@ -417,6 +427,7 @@ def main():
     model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # the generator's default; 0 = serial launch order (A/B runs)
     from lama_amd import ffc as _ffc
     _ffc._DEFAULT_EXEC.local_first = bool(int(os.environ.get('LAMA_LOCAL_FIRST', '1')))
+    _ffc._DEFAULT_EXEC.winograd = bool(int(os.environ.get('LAMA_WINOGRAD', '1')))            # the generator's default; 0 for A/B runs
     model.generator.pipeline_local = bool(int(os.environ.get('LAMA_PIPELINE_LOCAL', '0')))   # the generator's default; 1 for A/B runs
     model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '0')))         # the generator's default; 1 for A/B runs
     img, mask = synthetic_batch(device, 1234 + rank)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 105
+#define LAMA_HIP_VERSION 106
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -124,6 +124,23 @@ int64_t lama_conv2d_packed_weight_bytes(int32_t cout, int32_t cin, int32_t kh, i
 int lama_conv2d_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t kh,
                             int32_t kw, int32_t stride, int32_t transposed, int32_t precision, void* dst);
 int lama_conv2d_fwd(void* stream, const lama_conv2d_args* args);
+
+/* Winograd F(2x2, 3x3) form of a 3x3 / stride 1 / reflect-pad 1 convolution: the SAME function as lama_conv2d_fwd on such a layer
+ * (FFC.convl2l + convg2l over the 512-channel bottleneck state -> the 128 local output channels, ffc.py:188-196,220, with the folded
+ * BatchNorm + ReLU of FFC_BN_ACT, ffc.py:251-255, and the FFCResnetBlock residual, ffc.py:288), computed with 16 instead of 36
+ * multiplies per 2 x 2 output tile and (output, input) channel pair -- the launch is bound by the power the matrix cores draw, so
+ * fewer MFMA products is what shortens it.  Split precisions only (LAMA_PREC_F16X3 / BF16X3; the 3-term split is applied to the
+ * transformed operands: 1.2e-5 max-abs end to end with every such conv of the generator in this form); fp32 tensors; Cin % 32 == 0,
+ * Cout % 128 == 0, W in {32, 64, 128, 256}, H a multiple of 512 / W.  Anything else: LAMA_ERR_UNSUPPORTED (use lama_conv2d_fwd).
+ *   lama_winograd_pack_weight: Conv2d weights [Cout, Cin, 3, 3] -> U = G g G^T per channel pair, BatchNorm scale folded, (hi, lo)
+ *     split, MFMA A-fragment order; lama_winograd_packed_weight_bytes bytes.
+ *   lama_winograd_conv3x3_fwd: args as lama_conv2d_fwd (x, w_packed, bias, act, resid, y, batch, precision, range_flag; kh = kw = 3,
+ *     stride = 1, pad = 1, pad_mode = LAMA_PAD_REFLECT); workspace = lama_winograd_workspace_bytes device bytes (the half-inverted
+ *     transform-domain sums between its two launches). */
+int64_t lama_winograd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t precision);
+int lama_winograd_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t precision, void* dst);
+size_t lama_winograd_workspace_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W);
+int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* args, void* workspace, size_t workspace_bytes);
 
 /* torch.fft.rfftn(x, dim=(-2,-1), norm='ortho') followed by the Re/Im channel interleave
  * (ffc.py:86-89): x [B,C,h,w] -> spec [B,2C,h,w/2+1], channel 2c = Re, 2c+1 = Im. */

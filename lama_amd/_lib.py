@@ -17,7 +17,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 CONV_COOPERATIVE = 1
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 105      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 106      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -124,6 +124,10 @@ class LamaLib:
         L.lama_ssim_workspace_bytes.restype, L.lama_ssim_workspace_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
         L.lama_ssim_fwd.restype, L.lama_ssim_fwd.argtypes = C.c_int, [vp, T, T, i32, i32, C.POINTER(C.c_float), vp, vp, C.c_size_t]
         L.lama_fuse1_channel_order.restype, L.lama_fuse1_channel_order.argtypes = None, [C.POINTER(C.c_int32)]
+        L.lama_winograd_packed_weight_bytes.restype, L.lama_winograd_packed_weight_bytes.argtypes = C.c_int64, [i32, i32, i32]
+        L.lama_winograd_pack_weight.restype, L.lama_winograd_pack_weight.argtypes = C.c_int, [vp, vp, vp, i32, i32, i32, vp]
+        L.lama_winograd_workspace_bytes.restype, L.lama_winograd_workspace_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
+        L.lama_winograd_conv3x3_fwd.restype, L.lama_winograd_conv3x3_fwd.argtypes = C.c_int, [vp, C.POINTER(Conv2dArgs), vp, C.c_size_t]
         del dp
         if L.lama_version() != ABI_VERSION:
             raise LamaError(f'{path}: ABI version {L.lama_version()} != {ABI_VERSION}')
@@ -192,6 +196,51 @@ class LamaLib:
             a.fuse1_w, a.fuse1_bias, a.fuse1_y = fuse1[0].data_ptr(), fuse1[1].data_ptr(), fuse1[2]
         a.flags = CONV_COOPERATIVE if cooperative else 0      # another stream runs beside this launch (lama_conv2d_args.flags)
         self.check(self._l.lama_conv2d_fwd(stream, C.byref(a)), 'lama_conv2d_fwd')
+
+    # -- Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect conv (lama_winograd_*) -----------------
+    def winograd_supported(self, cout: int, cin: int, H: int, W: int, precision: int) -> bool:
+        return (precision in (PREC_F16X3, PREC_BF16X3) and self._l.lama_winograd_packed_weight_bytes(cout, cin, precision) > 0
+                and self._l.lama_winograd_workspace_bytes(1, cout, H, W) > 0)
+
+    def winograd_workspace_bytes(self, batch: int, cout: int, H: int, W: int) -> int:
+        return int(self._l.lama_winograd_workspace_bytes(batch, cout, H, W))
+
+    def pack_winograd_weight(self, w: torch.Tensor, scale: Optional[torch.Tensor], precision: int) -> torch.Tensor:
+        """Conv2d weight [Cout, Cin, 3, 3] (+ folded BN scale) -> packed U = G g G^T fragments (lama_winograd_pack_weight)."""
+        if not self.host_emulated and not w.is_cuda:
+            raise LamaError('pack_winograd_weight: the weights are on the CPU: move the module to the GPU first')
+        w = w.contiguous().float()
+        cout, cin, kh, kw = w.shape
+        nbytes = self._l.lama_winograd_packed_weight_bytes(cout, cin, precision) if (kh, kw) == (3, 3) else -1
+        if nbytes <= 0:
+            raise LamaError(f'unsupported Winograd geometry {tuple(w.shape)} / precision {precision}', code=ERR_UNSUPPORTED)
+        if precision == PREC_F16X3 and w.numel():
+            ws = w if scale is None else w * scale.float().view(-1, 1, 1, 1)
+            amax = float(ws.abs().sum(dim=(2, 3)).max())        # |U| <= sum |g| (the rows of G have absolute sum <= 1.5, squared 2.25 > needed)
+            if not 2.25 * amax <= F16_MAX:
+                raise LamaRangeError(f'transformed conv weight bound {2.25 * amax:.3g} exceeds the fp16 split range ({F16_MAX}); use bf16x3')
+        dst = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+        sc = None if scale is None else scale.contiguous().float()
+        self.check(self._l.lama_winograd_pack_weight(self.stream_of(w), w.data_ptr(), None if sc is None else sc.data_ptr(), cout, cin,
+                                                     precision, dst.data_ptr()), 'lama_winograd_pack_weight')
+        if w.is_cuda:
+            torch.cuda.current_stream(w.device).synchronize()
+        return dst
+
+    def winograd_conv3x3(self, x: Tensor4, w_packed: torch.Tensor, y: Tensor4, batch: int, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                         act: int = ACT_NONE, resid: Optional[Tensor4] = None, precision: int = PREC_F16X3, stream: int = 0,
+                         range_flag: Optional[torch.Tensor] = None):
+        a = Conv2dArgs()
+        a.x, a.w_packed = x, w_packed.data_ptr()
+        a.kh = a.kw = 3
+        a.stride, a.pad, a.pad_mode, a.transposed = 1, 1, PAD_REFLECT, 0
+        a.bias = None if bias is None else bias.data_ptr()
+        a.act = act
+        if resid is not None:
+            a.resid = resid
+        a.y, a.batch, a.precision = y, batch, precision
+        a.range_flag = None if range_flag is None else range_flag.data_ptr()
+        self.check(self._l.lama_winograd_conv3x3_fwd(stream, C.byref(a), ws.data_ptr(), ws.numel() * ws.element_size()), 'lama_winograd_conv3x3_fwd')
 
     def fuse1_channel_order(self) -> torch.Tensor:
         """Input-channel order of a conv1 weight that rides in another launch's epilogue (lama_fuse1_channel_order)."""

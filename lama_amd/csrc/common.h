@@ -85,6 +85,13 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #define LAMA_CYCLES() ((long long)__builtin_readcyclecounter())   // s_memtime (k-step stamps of the profiling tools)
 #endif
 
+// x - float(h) for the two fp16 halves of a packed word in ONE VALU instruction each (v_fma_mix_f32 reads an fp16 half directly;
+// hipcc emits v_cvt_f32_f16 + v_sub_f32 for the same expression).  (tests/hipemu overrides these for the host build.)
+#ifndef LAMA_F16_RESIDUAL_LO
+#define LAMA_F16_RESIDUAL_LO(d, packed, x) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(x))
+#define LAMA_F16_RESIDUAL_HI(d, packed, x) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(x))
+#endif
+
 // LDS hand-off between the lanes of ONE wave (wave-private LDS regions, no workgroup barrier): the LDS pipe executes a wave's
 // instructions in order, so only the compiler has to be kept from moving accesses across this point.  (tests/hipemu maps it
 // to its per-wave barrier.)
@@ -114,3 +121,12 @@ LAMA_CB_DECL(_bf16x3)
 LAMA_CB_DECL(_f16x3)
 LAMA_CB_DECL(_f16)
 #undef LAMA_CB_DECL
+// Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect convolution (wino_dev.inc), reached through lama_winograd_* with LAMA_PREC_BF16X3 / F16X3
+#define LAMA_WG_DECL(sfx)                                                                                                          \
+    int64_t lama_cb_wino_packed_weight_bytes##sfx(int cout, int cin);                                                               \
+    int lama_cb_wino_pack_weight##sfx(hipStream_t stream, const float* w, const float* scale, int cout, int cin, void* dst);         \
+    int64_t lama_cb_wino_workspace_bytes##sfx(int batch, int cout, int H, int W);                                                    \
+    int lama_cb_wino_fwd##sfx(hipStream_t stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes);
+LAMA_WG_DECL(_bf16x3)
+LAMA_WG_DECL(_f16x3)
+#undef LAMA_WG_DECL

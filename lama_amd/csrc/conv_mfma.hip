@@ -472,6 +472,37 @@ extern "C" int lama_conv2d_pack_weight(void* stream, const float* w, const float
 // packed K position k = 16 kq + 8 khalf + i of lama_conv2d_args.fuse1_w holds input channel 32 F + 16 ks + 8 (i / 4) + 4 khalf + i % 4 with
 // kq = 2 F + ks: the row (r & 3) + 8 (r >> 2) + 4 khalf that accumulator register r = 8 ks + i of lane half khalf holds in the
 // 32-row fragment F of the producing kernel (conv_wreg_dev.inc)
+// ---- Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect convolution (wino_dev.inc): split precisions only -------------------------
+extern "C" int64_t lama_winograd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t precision) {
+    if (precision == LAMA_PREC_BF16X3) return lama_cb_wino_packed_weight_bytes_bf16x3(cout, cin);
+    if (precision == LAMA_PREC_F16X3) return lama_cb_wino_packed_weight_bytes_f16x3(cout, cin);
+    return LAMA_ERR_UNSUPPORTED;
+}
+
+extern "C" int lama_winograd_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t precision, void* dst) {
+    if (!w || !dst || cout <= 0 || cin <= 0) return LAMA_ERR_BAD_ARG;
+    if (precision == LAMA_PREC_BF16X3) return lama_cb_wino_pack_weight_bf16x3((hipStream_t)stream, w, scale, cout, cin, dst);
+    if (precision == LAMA_PREC_F16X3) return lama_cb_wino_pack_weight_f16x3((hipStream_t)stream, w, scale, cout, cin, dst);
+    return LAMA_ERR_UNSUPPORTED;
+}
+
+extern "C" size_t lama_winograd_workspace_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W) {
+    const int64_t n = lama_cb_wino_workspace_bytes_f16x3(batch, cout, H, W);     // the same for both split precisions
+    return n > 0 ? (size_t)n : 0;
+}
+
+extern "C" int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes) {
+    if (!a || !tensor_ok(a->x) || !tensor_ok(a->y) || !a->w_packed || a->batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad != 1 || a->pad_mode != LAMA_PAD_REFLECT || a->transposed) return LAMA_ERR_UNSUPPORTED;
+    if (a->x2.ptr || a->fuse1_w) return LAMA_ERR_UNSUPPORTED;
+    if (a->x.dtype != LAMA_DT_F32 || a->y.dtype != LAMA_DT_F32 || (a->resid.ptr && a->resid.dtype != LAMA_DT_F32)) return LAMA_ERR_UNSUPPORTED;
+    if (a->x.H != a->y.H || a->x.W != a->y.W || a->x.H < 2 || a->x.W < 2) return LAMA_ERR_BAD_ARG;
+    if (a->resid.ptr && (a->resid.C != a->y.C || a->resid.H != a->y.H || a->resid.W != a->y.W)) return LAMA_ERR_BAD_ARG;
+    if (a->precision == LAMA_PREC_BF16X3) return lama_cb_wino_fwd_bf16x3((hipStream_t)stream, a, workspace, workspace_bytes);
+    if (a->precision == LAMA_PREC_F16X3) return lama_cb_wino_fwd_f16x3((hipStream_t)stream, a, workspace, workspace_bytes);
+    return LAMA_ERR_UNSUPPORTED;
+}
+
 extern "C" void lama_fuse1_channel_order(int32_t* order) {
     for (int kq = 0; kq < 24; ++kq)
         for (int kh = 0; kh < 2; ++kh)

@@ -125,6 +125,7 @@ class _Exec:
         self._depth = 0
         self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
+        self.winograd = True              # the local 3x3 conv of a two-branch FFC layer as Winograd F(2x2, 3x3) where the shape allows (wino_dev.inc)
         self.local_first = True           # capture order at the fork: the first successor of a hipGraph node stays on its queue
         self.cooperative_serial = False   # tests: the one-stream launch order with the overlapped order's kernel geometry (bit-equal results)
 
@@ -172,6 +173,10 @@ class _Exec:
     def fourier_unit(self, *a, precision: int = L.PREC_F32, stream: int = 0):
         flag = self._cur_flag if precision in (L.PREC_F16X3, L.PREC_F16) else None
         self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag)
+
+    def winograd_conv3x3(self, *a, precision: int = L.PREC_F16X3, **kw):
+        flag = self._cur_flag if precision == L.PREC_F16X3 else None
+        self.lib.winograd_conv3x3(*a, precision=precision, range_flag=flag, **kw)
 
 
 _DEFAULT_EXEC = _Exec()
@@ -407,6 +412,14 @@ class FFC(_HipModule):
             # local output: conv over the whole state buffer [x_l | x_g] with [convl2l , convg2l] stacked along Cin
             w_lout = torch.cat([f.convl2l.weight.detach(), f.convg2l.weight.detach()], dim=1)
             pk['w_lout'] = lib.pack_conv_weight(w_lout, sl, precision=prec)
+            # ... and in Winograd F(2x2, 3x3) form (16 instead of 36 MFMA products per 2 x 2 tile; lama_winograd_*), used by launch() where the
+            # plane shape allows; a transformed weight beyond the fp16 range keeps the direct kernel
+            if (f.kernel_size == 3 and f.stride == 1 and f.padding == 1 and prec in (L.PREC_F16X3, L.PREC_BF16X3)
+                    and w_lout.shape[0] % 128 == 0 and w_lout.shape[1] % 32 == 0):
+                try:
+                    pk['w_lout_wino'] = lib.pack_winograd_weight(w_lout, sl, prec)
+                except LamaRangeError:
+                    pass
             pk['b_l'] = None if bl is None else bl.contiguous()
             pk['w_l2g'] = lib.pack_conv_weight(f.convl2g.weight.detach(), sg, precision=prec)
             pk['b_g'] = None if bg is None else bg.contiguous()
@@ -443,11 +456,24 @@ class FFC(_HipModule):
             return False
         cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
         spec = f.convg2g
+        # (not with the join-free chain of local convs, SidePipe: consecutive layers' local convs may overlap and share scratch['wino'])
+        wino = (ex.winograd and pad == 1 and 'w_lout_wino' in pk and scratch is not None and scratch.get('wino') is not None
+                and src.dtype == torch.float32 and dst.dtype == torch.float32 and not isinstance(side, SidePipe))
+
+        def local_conv(stream, cooperative):
+            """out_xl = act(bn(convl2l(x_l) + convg2l(x_g))) [+ residual]: one 3x3 over the whole state buffer (ffc.py:220)."""
+            rl = None if resid is None else L.view(resid, 0, ocl)
+            if wino:
+                ex.winograd_conv3x3(L.view(src), pk['w_lout_wino'], L.view(dst, 0, ocl), B, scratch['wino'], pk['b_l'], act, rl, precision=prec,
+                                    stream=stream)
+            else:
+                ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act, rl, precision=prec,
+                          stream=stream, cooperative=cooperative)
+
         if isinstance(side, SidePipe) and src.is_cuda:
             main = torch.cuda.current_stream(src.device)
             side.stream.wait_stream(main)               # the previous layer's global launch (x_g) -- and every reader of dst's x_l slice
-            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
-                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=side.stream.cuda_stream, cooperative=True)
+            local_conv(side.stream.cuda_stream, True)
             done = torch.cuda.Event()
             done.record(side.stream)
             spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
@@ -459,15 +485,13 @@ class FFC(_HipModule):
             side.wait_stream(main)                      # fork: src (and the scratch buffers' last readers) are ordered before
             if not ex.local_first:
                 spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
-            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
-                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st, cooperative=True)
+            local_conv(st, True)
             if ex.local_first:
                 spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
             main.wait_stream(side)                      # join: t is ready for the global conv
         else:
             spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
-            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act,
-                      None if resid is None else L.view(resid, 0, ocl), precision=prec, stream=st, cooperative=ex.cooperative_serial)
+            local_conv(st, ex.cooperative_serial)
         # the global branch; by the time it runs this layer's own x1 has been consumed (rfft2 and the x + fu(x) add are upstream of t)
         fuse1 = None
         shape_key = (tuple(src.shape), prec)
@@ -504,7 +528,12 @@ class FFC(_HipModule):
         B, _, H, W = src_shape
         half = self.convg2g.conv2.in_channels
         x1 = torch.empty(B, half, H, W, device=device, dtype=_act_dtype(self.precision))
-        return dict(x1=x1, t=torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
+        sc = dict(x1=x1, t=torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
+        lib = self._exec.lib
+        if (self._exec.winograd and self.kernel_size == 3 and self.stride == 1 and self.padding == 1 and self.out_cl
+                and lib.winograd_supported(self.out_cl, self.in_cl + self.in_cg, H, W, self.precision)):
+            sc['wino'] = torch.empty(lib.winograd_workspace_bytes(B, self.out_cl, H, W) // 4, device=device, dtype=torch.float32)
+        return sc
 
     def forward(self, x):
         """The bare FFC of ffc.py:205-225 (no BatchNorm, no activation): (x_l, x_g) -> (out_xl, out_xg), same launches as the

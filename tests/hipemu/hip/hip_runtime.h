@@ -141,6 +141,25 @@ static inline T __shfl(T v, int src, int width = 64) {
     memcpy(&r, all[base + (src % width + width) % width], sizeof(T));
     return r;
 }
+// v_mov_b32_dpp with a whole-wave shift by one lane (gfx9: wave_shl:1 = 0x130, wave_shr:1 = 0x138), bound_ctrl = 0 for the lane without
+// a source.  wave_shr:1: lane i reads lane i - 1;  wave_shl:1: lane i reads lane i + 1.
+template <class T>
+static inline T hipemu_update_dpp(T oldv, T src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    uint32_t mine[1];
+    static_assert(sizeof(T) == 4, "dpp moves dwords");
+    memcpy(mine, &src, 4);
+    auto all = hipemu::exchange(mine, 1);
+    const int l = hipemu::lane();
+    const int from = ctrl == 0x138 ? l - 1 : (ctrl == 0x130 ? l + 1 : -2);
+    if (from == -2) { std::fprintf(stderr, "hipemu: dpp ctrl 0x%x not emulated\n", ctrl); std::abort(); }
+    (void)row_mask; (void)bank_mask;
+    if (from < 0 || from > 63) return bound_ctrl ? T(0) : oldv;
+    T r;
+    memcpy(&r, all[from], 4);
+    return r;
+}
+#define __builtin_amdgcn_update_dpp(o, s, ctrl, rm, bm, bc) hipemu_update_dpp(o, s, ctrl, rm, bm, bc)
+
 template <class T>
 static inline T __shfl_xor(T v, int mask, int width = 64) { return __shfl(v, (hipemu::lane() % width) ^ mask, width); }
 template <class T>
@@ -291,6 +310,14 @@ static inline void hipemu_buf_store_b16(lama_buf_t r, unsigned short v, unsigned
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) hipemu_buf_load_b128(rsrc, voff, soff)
+static inline float hipemu_f16_residual(unsigned packed, float x, int hi) {
+    unsigned short b = (unsigned short)(hi ? packed >> 16 : packed & 0xffffu);
+    _Float16 h;
+    memcpy(&h, &b, 2);
+    return fmaf((float)h, -1.0f, x);
+}
+#define LAMA_F16_RESIDUAL_LO(d, packed, x) ((d) = hipemu_f16_residual(packed, x, 0))
+#define LAMA_F16_RESIDUAL_HI(d, packed, x) ((d) = hipemu_f16_residual(packed, x, 1))
 #define LAMA_WAVE_UNIFORM(x) (x)
 #define LAMA_WAVE_SYNC() hipemu::wave_barrier()
 #define LAMA_CLOCK() 0ll

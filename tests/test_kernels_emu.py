@@ -453,3 +453,50 @@ def test_conv2d_fp16_fused_second_operand_wreg_emulated(cg_, sdt, odt):
 @pytest.mark.parametrize('case,xdt,ydt', F16_STEM_HEAD, ids=['stem_f32_to_f16', 'head_f16_to_f32'])
 def test_conv2d_fp16_stem_head_emulated(case, xdt, ydt):
     _run_f16_case(emu_lib(), case, xdt, ydt)
+
+
+# Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect conv (wino_dev.inc): W = 32 / 64 (bands of 8 / 4 tile rows), one and two bands,
+# one and two 128-row groups, 32 and 64 input channels (one / two chunks), with and without bias / activation / residual
+WINO_CASES = [
+    dict(cin=32, cout=128, H=16, W=32, B=1, act=1, bias=True, resid=True, scale=True),
+    dict(cin=64, cout=128, H=16, W=64, B=2, act=0, bias=False, resid=False, scale=False),
+    dict(cin=32, cout=256, H=8, W=64, B=1, act=1, bias=True, resid=False, scale=True),
+]
+
+
+@pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
+@pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: f"c{c['cin']}o{c['cout']}_{c['H']}x{c['W']}b{c['B']}")
+def test_winograd_conv3x3_emulated(case, prec):
+    """lama_winograd_conv3x3_fwd against the plain torch conv (reflect pad 1) -- the same function as lama_conv2d_fwd on this layer --
+    and against the direct HIP kernel on the same inputs."""
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(5)
+    B, cin, cout, H, W = case['B'], case['cin'], case['cout'], case['H'], case['W']
+    x = torch.randn(B, cin + 2, H, W, generator=g)[:, 1:1 + cin]            # a channel slice of a wider buffer
+    xbuf = torch.zeros(B, cin + 2, H, W)
+    xbuf[:, 1:1 + cin] = x
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.2
+    scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
+    bias = torch.randn(cout, generator=g) if case['bias'] else None
+    ref0 = _conv_ref(x, w, 1, 1, True, False, None, 0, None, scale=scale)
+    resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
+    ref = _conv_ref(x, w, 1, 1, True, False, bias, case['act'], resid, scale=scale)
+    assert lib.winograd_supported(cout, cin, H, W, prec) and not lib.winograd_supported(cout, cin, H, 48, prec)
+    assert not lib.winograd_supported(cout, cin, H, W, L.PREC_F32) and not lib.winograd_supported(96, cin, H, W, prec)
+    wp = lib.pack_winograd_weight(w, scale, prec)
+    ws = torch.zeros(lib.winograd_workspace_bytes(B, cout, H, W) // 4)
+    ybuf = torch.full((B, cout + 3, H, W), 7.0)
+    flag = torch.zeros(1, dtype=torch.int32)
+    lib.winograd_conv3x3(L.view(xbuf, 1, cin), wp, L.view(ybuf, 2, cout), B, ws, bias, case['act'], None if resid is None else L.view(resid),
+                         precision=prec, range_flag=flag)
+    y = ybuf[:, 2:2 + cout]
+    tol = dict(atol=1.2e-3, rtol=4e-4) if prec == L.PREC_BF16X3 else dict(atol=3e-4, rtol=1e-4)   # sums of 4 inputs x transformed weights: 2x the direct kernel's bound
+    assert torch.allclose(y, ref, **tol), float((y - ref).abs().max())
+    assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0 and int(flag) == 0
+    wd = lib.pack_conv_weight(w, scale, precision=prec)
+    yd = torch.zeros(B, cout, H, W)
+    lib.conv2d(L.view(xbuf, 1, cin), wd, L.view(yd), B, 3, 1, 1, L.PAD_REFLECT, False, bias, case['act'], None if resid is None else L.view(resid),
+               precision=prec)
+    assert float((y - yd).abs().max()) < 2 * tol['atol']
+    with pytest.raises(L.LamaError):                                         # workspace too small
+        lib.winograd_conv3x3(L.view(xbuf, 1, cin), wp, L.view(ybuf, 2, cout), B, ws[:16], bias, case['act'], None, precision=prec)

@@ -10,7 +10,7 @@ from lama_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 
-from tests.test_kernels_emu import (CONV_CASES, CONV_TOL, F16_CASES, F16_MIXED, F16_STEM_HEAD, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_f16_ref, _conv_ref,  # noqa: E402
+from tests.test_kernels_emu import (WINO_CASES, CONV_CASES, CONV_TOL, F16_CASES, F16_MIXED, F16_STEM_HEAD, FFT_SIZES, PREC_IDS, PRECISIONS, _conv_f16_ref, _conv_ref,  # noqa: E402
                                     _inv_ref, _spec_ref)
 
 
@@ -634,3 +634,44 @@ def test_rfft2_irfft2_fp16_io(lib, hw):
     lib.irfft2(L.view(s2d), L.view(rd), L.view(y), B, ws, stream=st)
     ref2 = resid.float() + _inv_ref(spec2.float(), h, w)
     assert torch.allclose(y.float().cpu(), ref2, atol=4e-3, rtol=2e-3)
+
+
+@pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
+@pytest.mark.parametrize('case', WINO_CASES + [dict(cin=512, cout=128, H=64, W=64, B=8, act=1, bias=True, resid=True, scale=True),
+                                               dict(cin=512, cout=128, H=128, W=128, B=2, act=1, bias=True, resid=True, scale=True),
+                                               dict(cin=64, cout=128, H=32, W=256, B=1, act=0, bias=False, resid=False, scale=False)],
+                         ids=lambda c: f"c{c['cin']}o{c['cout']}_{c['H']}x{c['W']}b{c['B']}")
+def test_winograd_conv3x3(lib, case, prec):
+    """lama_winograd_conv3x3_fwd (Winograd F(2x2, 3x3), wino_dev.inc) against the plain torch conv and the direct HIP kernel, incl. the
+    bottleneck's local conv at BASELINE configs[1] / configs[2] shapes (8 x 512 -> 128 at 64 x 64, 2 x the same at 128 x 128)."""
+    g = torch.Generator().manual_seed(5)
+    B, cin, cout, H, W = case['B'], case['cin'], case['cout'], case['H'], case['W']
+    xbuf = torch.randn(B, cin + 2, H, W, generator=g)
+    x = xbuf[:, 1:1 + cin]
+    w = torch.randn(cout, cin, 3, 3, generator=g) * (0.2 if cin <= 64 else 0.03)
+    scale = torch.rand(cout, generator=g) + 0.5 if case['scale'] else None
+    bias = torch.randn(cout, generator=g) if case['bias'] else None
+    ref0 = _conv_ref(x, w, 1, 1, True, False, None, 0, None, scale=scale)
+    resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
+    ref = _conv_ref(x, w, 1, 1, True, False, bias, case['act'], resid, scale=scale)
+    assert lib.winograd_supported(cout, cin, H, W, prec)
+    wp = lib.pack_winograd_weight(w.to(DEV), None if scale is None else scale.to(DEV), prec)
+    ws = torch.zeros(lib.winograd_workspace_bytes(B, cout, H, W) // 4, device=DEV)
+    ybuf = torch.full((B, cout + 3, H, W), 7.0, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    xd, rd, bd = xbuf.to(DEV), None if resid is None else resid.to(DEV), None if bias is None else bias.to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.winograd_conv3x3(L.view(xd, 1, cin), wp, L.view(ybuf, 2, cout), B, ws, bd, case['act'], None if rd is None else L.view(rd), precision=prec,
+                         stream=st, range_flag=flag)
+    torch.cuda.synchronize()
+    y = ybuf[:, 2:2 + cout].cpu()
+    tol = dict(atol=1.2e-3, rtol=4e-4) if prec == L.PREC_BF16X3 else dict(atol=3e-4, rtol=1e-4)
+    assert torch.allclose(y, ref, **tol), float((y - ref).abs().max())
+    assert float(ybuf[:, :2].min()) == 7.0 and float(ybuf[:, -1].max()) == 7.0 and int(flag) == 0
+    wd = lib.pack_conv_weight(w.to(DEV), None if scale is None else scale.to(DEV), precision=prec)
+    yd = torch.zeros(B, cout, H, W, device=DEV)
+    lib.conv2d(L.view(xd, 1, cin), wd, L.view(yd), B, 3, 1, 1, L.PAD_REFLECT, False, bd, case['act'], None if rd is None else L.view(rd), precision=prec, stream=st)
+    torch.cuda.synchronize()
+    err_w, err_d = float((y - ref).abs().max()), float((yd.cpu() - ref).abs().max())
+    print(f'winograd max-abs {err_w:.2e} (mean {float((y - ref).abs().mean()):.2e}); direct kernel {err_d:.2e}')
+    assert err_w < 4 * max(err_d, 2e-5)

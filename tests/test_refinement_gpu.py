@@ -118,8 +118,7 @@ def test_refine_predict_biglama_golden(biglama_module, golden_dir, res, precs):
     golden file therefore carries the algorithm's OWN sensitivity: the oracle re-run with the initial features perturbed by a relative
     2e-6 (two valid fp32 evaluations of the front layers differ by that much) lands 1.14e-3 mean-abs / 3.3e-2 max-abs from the golden
     output at the 1024 scale while its loss curve stays within 9e-6 -- and the HIP path lands 1.15e-3 / 3.3e-2 / 1.1e-5 from it, in
-    exact fp32 and in the default precision alike (profiles/r03_refine_parity.txt).  Bars: every loss within 1e-4 of the oracle's
-    (10x the self-sensitivity) and monotonically falling; the refined image within 2x the oracle's self-distance (mean and max; floors
+    exact fp32 and in the default precision alike (profiles/r03_refine_parity.txt).  Bars: every loss within max(1e-4, 4x the self-sensitivity) of the oracle's and monotonically falling; the refined image within 2x the oracle's self-distance (mean and max; floors
     3e-4 / 5e-3, which the first scale -- a plain forward -- meets by three orders of magnitude); and clearly different from the
     un-refined forward (so "did nothing" cannot pass)."""
     path = os.path.join(golden_dir, f'refine_biglama_{res}.npz')
@@ -151,7 +150,8 @@ def test_refine_predict_biglama_golden(biglama_module, golden_dir, res, precs):
         if len(ref_loss):
             rel = np.abs(got - ref_loss) / ref_loss
             report.append(f'scale {s}: max loss rel err {rel.max():.2e}')
-            assert rel.max() < 1e-4, (s, got, ref_loss)
+            self_rel = float(g[f'self{s}'][2]) if f'self{s}' in g.files else 0.0
+            assert rel.max() < max(1e-4, 4 * self_rel), (s, got, ref_loss)
             assert np.all(np.diff(got) < 0)
         o = trace[s]['out']
         st = o.shape[-1] // g[f'out{s}_sample'].shape[-1]

@@ -49,6 +49,14 @@ def main():
                                   L.ACT_RELU, None if resid is None else L.view(resid), None if x2 is None else L.view(x2), w2p, precision=prec,
                                   stream=st, fuse1=None if f1 is None else f1[:3], cooperative=coop)
 
+    def wino(cin, cout, H, W):
+        x = rnd(B, cin, H, W)
+        wp = lib.pack_winograd_weight(rnd(cout, cin, 3, 3) * 0.03, None, prec)
+        y = torch.empty(B, cout, H, W, device=dev)
+        bias, resid = rnd(cout), rnd(B, cout, H, W)
+        ws = torch.empty(lib.winograd_workspace_bytes(B, cout, H, W), dtype=torch.uint8, device=dev)
+        return lambda: lib.winograd_conv3x3(L.view(x), wp, L.view(y), B, ws, bias, L.ACT_RELU, L.view(resid), precision=prec, stream=st)
+
     def fu_rot():
         # FourierUnit.forward (ffc.py:76-113) as lama_fourier_unit_fwd, KPROBE_ROT operand sets used round-robin so that a call does
         # not find its operands of the previous call in the 256 MiB Infinity Cache (default 6 sets x ~130 MB)
@@ -86,6 +94,8 @@ def main():
         'stem': lambda: conv(4, 64, 7, 512, 512),
         'head': lambda: conv(64, 3, 7, 512, 512),
         'fu': lambda: fu_rot(),
+        'wino': lambda: wino(512, 128, h, w),              # the local conv (convA) as Winograd F(2x2, 3x3): lama_winograd_conv3x3_fwd
+        'wino128': lambda: wino(512, 128, 128, 128),
         'rfft': lambda: (lambda: lib.rfft2(L.view(x1), L.view(spec), B, None, st)),
         'irfft': lambda: (lambda: lib.irfft2(L.view(spec), L.view(x1), L.view(y), B, None, st)),
     }
