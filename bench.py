@@ -429,7 +429,9 @@ def main():
     _ffc._DEFAULT_EXEC.local_first = bool(int(os.environ.get('LAMA_LOCAL_FIRST', '1')))
     _ffc._DEFAULT_EXEC.winograd = bool(int(os.environ.get('LAMA_WINOGRAD', '1')))            # the generator's default; 0 for A/B runs
     model.generator.pipeline_local = bool(int(os.environ.get('LAMA_PIPELINE_LOCAL', '0')))   # the generator's default; 1 for A/B runs
-    model.generator.fuse_conv1 = bool(int(os.environ.get('LAMA_FUSE_CONV1', '0')))         # the generator's default; 1 for A/B runs
+    if 'LAMA_FUSE_CONV1' in os.environ:                                                      # default None = by launch order (FFCResNetGenerator._build_plan); 0 / 1 force it (A/B runs)
+        model.generator.fuse_conv1 = bool(int(os.environ['LAMA_FUSE_CONV1']))
+    model.generator.serial_with_winograd = bool(int(os.environ.get('LAMA_SERIAL_WINOGRAD', '1')))
     img, mask = synthetic_batch(device, 1234 + rank)
     u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8, device=device)
     # The only data-path collective: the u8 output images (6.3 MB per rank).  It runs OFF the compute stream: the u8 batch of step k is

@@ -80,6 +80,7 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #define LAMA_BUF_STORE_B16(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(val), rsrc, voff, soff, 0)
 // out-of-range buffer stores are dropped: a predicated store without a branch
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b32(val, rsrc, voff, soff, 0)
+#define LAMA_BUF_STORE_B128(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, voff, soff, 0)   // val: 4 x u32 vector
 #define LAMA_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define LAMA_CLOCK() ((long long)wall_clock64())   // 100 MHz constant counter (timeline traces of the profiling tools)
 #define LAMA_CYCLES() ((long long)__builtin_readcyclecounter())   // s_memtime (k-step stamps of the profiling tools)

@@ -870,7 +870,10 @@ class FFCResNetGenerator(_HipModule):
         # global branch of the previous layer): 35 of 36 pointwise launches less per forward.  Worth -10 us per layer in
         # serial launch order; off by default since the second stream hides the stand-alone conv1 beside the cooperative local conv
         # (705 -> 719 images/s without it, profiles/r02_ab_overlap_and_fuse1_final.txt)
-        self.fuse_conv1 = False
+        self.fuse_conv1 = None            # None = by launch order (below), True / False = forced
+        # with the Winograd local conv (FFC.launch) a plan runs on ONE stream with conv1 fused into the global launch (see _build_plan)
+        self.serial_with_winograd = True
+        self.fuse_conv1_serial = True
         # the local convs of the residual blocks as a chain of their own on the second stream (SidePipe) instead of a fork + join per
         # layer.  Off: inside a hipGraph ROCm 7.2 spreads that topology over three queues and every edge becomes a ~10 us cross-queue
         # signal (727 -> 695 images/s, profiles/r02_ab_pipeline_local.txt); bit-identical results either way.
@@ -954,8 +957,17 @@ class FFCResNetGenerator(_HipModule):
             else:
                 raise LamaError(f'no fused plan for layer {type(lay).__name__}; run generator.model layer by layer')
             i += 1
-        side = torch.cuda.Stream(device=device) if (self.overlap_streams and torch.device(device).type == 'cuda') else None
-        return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None, side=side)
+        # Launch order.  Where the residual blocks' local conv takes the Winograd kernel (scratch['wino']) the plan is ONE stream: that
+        # kernel holds a CU's whole register file (one wave per SIMD, 256 accumulator registers), so nothing of the spectral branch can run
+        # beside it and a second stream buys only cross-queue signals; in a one-stream order conv1 of the next layer is cheapest in the
+        # global launch's epilogue (round 3, same box: 716 / 714 / 720-724 images/s for two streams / one / one + fused conv1,
+        # profiles/r03_ab_launch_order.txt).  Elsewhere (planes the Winograd kernel does not take) the round-2 order stays: the spectral
+        # branch on a second stream beside the cooperative direct conv.
+        wino = bool(scratch and scratch.get('wino') is not None and self._exec.winograd)
+        serial = wino and self.serial_with_winograd
+        side = torch.cuda.Stream(device=device) if (self.overlap_streams and not serial and torch.device(device).type == 'cuda') else None
+        return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None, side=side,
+                    fuse=self.fuse_conv1 or (serial and self.fuse_conv1 is not False and self.fuse_conv1_serial))
 
     def _run_plan(self, plan, x):
         bufs = plan['bufs']
@@ -974,9 +986,10 @@ class FFCResNetGenerator(_HipModule):
                 x1_ready = False
             elif kind == 'res':
                 _, lay, s, t, d = st
-                nxt = steps[i + 1][1] if self.fuse_conv1 and i + 1 < len(steps) and steps[i + 1][0] == 'res' else None
+                fuse = plan.get('fuse', self.fuse_conv1)
+                nxt = steps[i + 1][1] if fuse and i + 1 < len(steps) and steps[i + 1][0] == 'res' else None
                 x1_ready = lay.run(B(s), B(t), B(d), plan['scratch'], side=pipe or plan['side'], x1_ready=x1_ready, next_block=nxt,
-                                   fuse=self.fuse_conv1)
+                                   fuse=fuse)
                 if pipe is not None and (i + 1 == len(steps) or steps[i + 1][0] != 'res'):
                     pipe.join()                     # the last local conv: everything downstream reads its x_l
             elif kind == 'up':

@@ -306,6 +306,11 @@ static inline void hipemu_buf_store_b16(lama_buf_t r, unsigned short v, unsigned
 }
 #define LAMA_BUF_LOAD_B16(rsrc, voff, soff) hipemu_buf_load_b16(rsrc, voff, soff)
 #define LAMA_BUF_STORE_B16(rsrc, val, voff, soff) hipemu_buf_store_b16(rsrc, (unsigned short)(val), voff, soff)
+static inline void hipemu_buf_store_b128(lama_buf_t r, hipemu_u32x4 v, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    if (o + 16 <= r.n) memcpy(const_cast<char*>(r.p) + o, &v, 16);
+}
+#define LAMA_BUF_STORE_B128(rsrc, val, voff, soff) hipemu_buf_store_b128(rsrc, val, voff, soff)
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) hipemu_buf_store_b32(rsrc, val, voff, soff)
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)

@@ -81,6 +81,8 @@ CONV_CASES = [
     dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True, wl_slots=1),   # 18 tiles: two rounds + 6 thirds
     dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=True, scale=False, wl_slots=1),   # 10 tiles: one round + 6 thirds, residual
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=31, act=1, bias=True, resid=False, scale=True, wl_slots=1),     # 14 tiles: one round + 6 whole left-overs
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=4, W=32, act=1, bias=True, resid=True, scale=True, wl=2),            # whole tiles only: 16-byte stores through the wave's LDS transpose
+    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=8, W=16, act=2, bias=True, resid=False, scale=False, wl_slots=1),   # ... two row groups, 8 tiles on 8 waves
     # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
     dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True),
     dict(cin=3, cout=40, k=7, stride=1, pad=3, H=6, W=20, act=0, bias=False, resid=False, scale=False),

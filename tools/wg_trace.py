@@ -43,3 +43,5 @@ print(f'start: median {rel[:, 0].median():.2f} max {rel[:, 0].max():.2f};  last 
 print(f'prologue (first chunk transformed): median {(rel[:, 1] - rel[:, 0]).median():.2f} max {(rel[:, 1] - rel[:, 0]).max():.2f}')
 print(f'K loop (16 chunks of 32 channels): median {(rel[:, 2] - rel[:, 1]).median():.2f} p90 {(rel[:, 2] - rel[:, 1]).quantile(0.9):.2f} max {(rel[:, 2] - rel[:, 1]).max():.2f}')
 print(f'exchange + half inverse + stores: median {(rel[:, 3] - rel[:, 2]).median():.2f} max {(rel[:, 3] - rel[:, 2]).max():.2f}')
+ck = t[:, 4:8].double()
+print(f'chunk 8, wave 0, shader clocks: region 0 median {(ck[:, 1] - ck[:, 0]).median():.0f}, region 1 {(ck[:, 2] - ck[:, 1]).median():.0f}, barrier wait {(ck[:, 3] - ck[:, 2]).median():.0f}, chunk {(ck[:, 3] - ck[:, 0]).median():.0f} (48 MFMAs = 1536 clocks per region)')
