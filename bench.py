@@ -594,13 +594,10 @@ def main():
             roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
                         traffic=(pmc_traffic(dom, args.precision) or {}).get('traffic_bytes'), traffic_detail=pmc_traffic(dom, args.precision),
                         avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
-                        measured='HIP events around every launch in 3 eager steps in SERIAL launch order (each kernel alone on the GPU; '
-                                 'with the kernel geometry of the timed region: the local conv as one 4-wave workgroup per CU, LAMA_CONV_COOPERATIVE).  '
-                                 'rocprofv3 of `LAMA_OVERLAP_STREAMS=0 python bench.py`: profiles/r02_kernel_stats.csv.  The timed region runs the spectral '
-                                 'branch (conv1, rfft2, spectral GEMM, irfft2: ~110 us alone) on a second stream BESIDE the local conv: that conv then '
-                                 'takes ~133 us instead of ~97 with the branch inside that time, and the step is 5 % shorter than in serial order '
-                                 '(rocprofv3 of the default command: profiles/r02_kernel_stats_overlap_on.csv; per-dispatch timeline: '
-                                 'profiles/r02_timeline_overlap_step.txt; DESIGN.md 4.12)',
+                        measured='HIP events around every launch in 3 eager steps after the timed region, on the launch stream, in the launch order of '
+                                 'the timed region (round 3: ONE stream for plans whose residual blocks take the Winograd local conv -- every kernel runs '
+                                 'alone on the GPU in the timed region too; conv1 of the next layer rides in this launch when the key says +next_conv1x1).  '
+                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r03_kernel_stats.csv',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
@@ -613,6 +610,20 @@ def main():
                 a2 = timer.flops[k2] / kern[k2]['avg_us'] / 1e6
                 roof['runner_up'] = dict(kernel=k2, achieved=round(a2, 2), frac=round(a2 / peak, 4), avg_us=round(kern[k2]['avg_us'], 2),
                                          launches_per_step=kern[k2]['n'] // 3)
+            # the local 3x3 conv of the FFC layers as Winograd F(2x2, 3x3) (two launches, timed together): same algorithmic FLOPs as the direct
+            # conv it replaces -- the point of the transform is that 16 / 36 of the MFMA products deliver them
+            wk = [k for k in getattr(timer, 'winograd_keys', ()) if k in kern]
+            if wk:
+                k3 = max(wk, key=lambda k: kern[k]['total_us'])
+                a3 = timer.flops[k3] / kern[k3]['avg_us'] / 1e6
+                roof['local_conv_winograd'] = dict(
+                    kernel=k3 + ' = wino_gemm_kernel + wino_out_kernel (lama_winograd_conv3x3_fwd)', achieved=round(a3, 2), frac=round(a3 / peak, 4),
+                    avg_us=round(kern[k3]['avg_us'], 2), launches_per_step=kern[k3]['n'] // 3, flops_per_launch=timer.flops[k3],
+                    mfma_products_frac=round(a3 / peak * 16.0 / 36.0, 4),
+                    traffic=(pmc_traffic(k3, args.precision) or {}).get('traffic_bytes'), traffic_detail=pmc_traffic(k3, args.precision),
+                    note='achieved / frac: algorithmic FLOPs of the 3x3 conv (2*M*N*K*9) over the time of both launches, against the same 833 TF '
+                         '3-product ceiling as the direct kernel it replaced (0.48 in round 2); mfma_products_frac: the matrix-core rate actually '
+                         'sustained, i.e. 16/36 of that (the transform removes 2.25x of the products)')
             if precision != L.PREC_F32:
                 sus = sustained_mfma_peak(device)
                 if sus and sus.get('value'):
