@@ -61,6 +61,12 @@ CONV_CASES = [
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=6, W=35, act=1, bias=True, resid=False, scale=True, transposed=True, cwt=2),
     dict(cin=128, cout=256, k=3, stride=2, pad=1, H=9, W=10, act=0, bias=False, resid=False, scale=False, transposed=True, cwt=2),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=6, W=35, act=1, bias=True, resid=False, scale=True, transposed=True, cwt=0),   # the fused launch on the same shape
+    # ... ConvTranspose2d as ONE launch of class-specialised waves (convt_dev.inc: cin % 32 == 0, cout % 64 == 0, W % 32 == 0, H % 4 == 0): one
+    # tile / one chunk; 2 x 2 tiles, two chunks, two 64-row groups; and the fused LDS-staged launch on the same shape (LAMA_CT=0)
+    dict(cin=32, cout=64, k=3, stride=2, pad=1, H=4, W=32, act=1, bias=True, resid=False, scale=True, transposed=True),
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True),
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True, ct=0),
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=3),   # 16 tiles on 3 persistent workgroups
     # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
     dict(cin=32, cout=128, k=3, stride=2, pad=1, H=16, W=70, act=1, bias=True, resid=False, scale=True),
     dict(cin=64, cout=200, k=3, stride=2, pad=1, H=11, W=37, act=0, bias=False, resid=True, scale=False),
@@ -99,9 +105,13 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
+    if 'ct' in case:
+        monkeypatch.setenv('LAMA_CT', str(case['ct']))
+    if 'ct_grid' in case:
+        monkeypatch.setenv('LAMA_CT_GRID', str(case['ct_grid']))
     if 'wl' in case:
         monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
     if 'wl_slots' in case:

@@ -42,9 +42,13 @@ DEV = 'cuda'
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d(anylib, case, prec, monkeypatch):
     lib = anylib
+    if 'ct' in case:
+        monkeypatch.setenv('LAMA_CT', str(case['ct']))
+    if 'ct_grid' in case:
+        monkeypatch.setenv('LAMA_CT_GRID', str(case['ct_grid']))
     if 'wl' in case:        # pointwise GEMM: the round-2 weights-in-registers kernel (profiling build switch)
         monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
     if 'wl_slots' in case:
