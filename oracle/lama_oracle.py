@@ -213,29 +213,32 @@ def generator_forward(x: Tensor, sd, cfg: dict, prefix: str = 'model.', calib=No
 
 
 class _HalfOperands:
-    """``torch.nn.functional`` with the operands of every conv rounded to fp16 (products exact, fp32 accumulation)."""
+    """``torch.nn.functional`` with the operands of every conv rounded to fp16 (products exact, fp32 accumulation);
+    ``weights=False``: only the activations are rounded (LAMA_PREC_F16 since round 3: the weights keep their hi + lo parts)."""
+
+    def __init__(self, weights: bool = True):
+        self.weights = weights
 
     def __getattr__(self, name):
         return getattr(torch.nn.functional, name)
 
-    @staticmethod
-    def conv2d(x, w, b=None, **kw):
-        return torch.nn.functional.conv2d(x.half().float(), w.half().float(), b, **kw)
+    def conv2d(self, x, w, b=None, **kw):
+        return torch.nn.functional.conv2d(x.half().float(), w.half().float() if self.weights else w, b, **kw)
 
-    @staticmethod
-    def conv_transpose2d(x, w, b=None, **kw):
-        return torch.nn.functional.conv_transpose2d(x.half().float(), w.half().float(), b, **kw)
+    def conv_transpose2d(self, x, w, b=None, **kw):
+        return torch.nn.functional.conv_transpose2d(x.half().float(), w.half().float() if self.weights else w, b, **kw)
 
 
-def generator_forward_fp16_emulated(x: Tensor, sd, cfg: dict, prefix: str = 'model.') -> Tensor:
+def generator_forward_fp16_emulated(x: Tensor, sd, cfg: dict, prefix: str = 'model.', weights: bool = True) -> Tensor:
     """What a half-precision run of the same network costs (BASELINE configs[2]; the reference never runs FFC in fp16,
     configs/training/trainer/any_gpu_large_ssim_ddp_final.yaml:13-16 keeps ``precision: 16`` commented out): every conv / GEMM of
     ``generator_forward`` with BOTH operands rounded to fp16, exact products, fp32 accumulation, everything else fp32.  This is
     the yardstick of the LAMA_PREC_F16 tests: the HIP path (fp16 tensors in HBM, BatchNorm folded before the rounding) is asked to
-    stay at this error level against the fp32 oracle, not at the fp32 paths' 2e-4."""
+    stay at this error level against the fp32 oracle, not at the fp32 paths' 2e-4.  ``weights=False``: only the conv INPUTS are
+    rounded -- the yardstick of the two-product form (hi + lo weights) the HIP path uses since round 3."""
     global F
     keep = F
-    F = _HalfOperands()
+    F = _HalfOperands(weights)
     try:
         return generator_forward(x, sd, cfg, prefix)
     finally:

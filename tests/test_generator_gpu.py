@@ -202,11 +202,13 @@ def test_biglama_high_res_square(big, res):
 @pytest.mark.parametrize('shape', [(4, 1024), (2, 512), (1, 256)], ids=['c3_4x1024', '2x512', '1x256'])
 def test_biglama_fp16_activation_path(shape):
     """BASELINE configs[2] (big-lama 1024x1024 batch=4 fp16): PREC_F16 = fp16 activations in HBM between the stem and the head (the
-    resnet blocks' residual stream stays fp32), fp16 weights, one MFMA product per MAC, fp32 accumulation and epilogues.  Every image
-    against the fp32 oracle.  Stated tolerance: 3e-2 max-abs and 1.5e-3 mean-abs on the sigmoid output, AND no worse than 1.5x what
-    half-precision operands cost the oracle itself (O.generator_forward_fp16_emulated: 9.9e-3 max-abs at 512^2, 1.7e-2 at 1024^2 on
-    this fixture, half of it from rounding the weights alone -- BASELINE.md expected ~5e-3 from a 256^2 probe; the error grows with the resolution).
-    The fp32-accurate paths are held to 2e-4 above.  Also: the captured graph reproduces the eager result, no range flag."""
+    resnet blocks' residual stream stays fp32), weights as hi + lo fp16 parts in registers / LDS (TWO MFMA products per MAC since round
+    3: the weights keep 22 bits and cost no HBM byte), fp32 accumulation and epilogues.  Every image against the fp32 oracle.
+    Same-box A/B at 4 x 1024^2 (profiles/r03_fp16_two_products.txt): one product 2.10e-2 max / 5.97e-4 mean, two products 1.68e-2 /
+    4.03e-4; the oracle itself with only its conv INPUTS rounded to fp16 (O.generator_forward_fp16_emulated(weights=False)) sits at
+    1.58e-2 max on this input: that is the floor of fp16 activations, the kernels are 6 % above it.  Stated tolerance: **5e-4 mean-abs
+    at every size; max-abs 1e-2 up to 512^2 and 2e-2 at 1024^2** (round 2: 3e-2), AND max-abs no worse than 1.25x that floor.  The
+    fp32-accurate paths are held to 2e-4 above.  Also: the captured graph reproduces the eager result, no range flag."""
     bn, res = shape
     cfg = O.BIG_LAMA
     if 'sd' not in _BIG_SD:
@@ -222,10 +224,11 @@ def test_biglama_fp16_activation_path(shape):
     d = (y.cpu() - ref).abs()
     err = d.amax(dim=(1, 2, 3))
     with torch.no_grad():
-        emu = torch.cat([O.generator_forward_fp16_emulated(x[i:i + 1], _BIG_SD['sd'], cfg) for i in range(bn)], 0)
+        emu = torch.cat([O.generator_forward_fp16_emulated(x[i:i + 1], _BIG_SD['sd'], cfg, weights=False) for i in range(bn)], 0)
     emu_err = (emu - ref).abs().amax(dim=(1, 2, 3))
-    assert float(err.max()) < 3e-2 and float(d.mean()) < 1.5e-3, (err.tolist(), float(d.mean()))
-    assert float(err.max()) < 1.5 * float(emu_err.max()), (err.tolist(), emu_err.tolist())
+    print(f'fp16 path {bn} x {res}^2: max-abs {float(err.max()):.2e} mean-abs {float(d.mean()):.2e}; oracle with fp16 conv inputs: {float(emu_err.max()):.2e}')
+    assert float(err.max()) < (1e-2 if res <= 512 else 2e-2) and float(d.mean()) < 5e-4, (err.tolist(), float(d.mean()))
+    assert float(err.max()) < 1.25 * float(emu_err.max()), (err.tolist(), emu_err.tolist())
     gen.use_graph = True
     yg = gen(xd)
     assert torch.equal(gen(xd), yg) and torch.equal(yg, y)

@@ -351,13 +351,14 @@ def test_rfft2_irfft2_fp16_io_emulated(hw):
 
 
 def _conv_f16_ref(x, w, stride, pad, reflect, transposed, bias, act, resid, x2=None, w2=None, scale=None):
-    """LAMA_PREC_F16: fp16 activations and fp16 (BatchNorm-folded) weights, exact products, fp32 accumulation / epilogue."""
+    """LAMA_PREC_F16: fp16 activations, BatchNorm-folded weights as hi + lo fp16 parts (two products per MAC: 22 mantissa bits of the
+    weights survive), exact products, fp32 accumulation / epilogue."""
     if scale is not None:
         w = w * (scale[None, :, None, None] if transposed else scale[:, None, None, None])
         if w2 is not None:
             w2 = w2 * scale[:, None, None, None]
-    return _conv_ref(x.float(), w.half().float(), stride, pad, reflect, transposed, bias, act, None if resid is None else resid.float(),
-                     x2=None if x2 is None else x2.float(), w2=None if w2 is None else w2.half().float())
+    return _conv_ref(x.float(), w, stride, pad, reflect, transposed, bias, act, None if resid is None else resid.float(),
+                     x2=None if x2 is None else x2.float(), w2=w2)
 
 
 F16_CASES = [
