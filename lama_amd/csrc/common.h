@@ -75,11 +75,13 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 }
 #define LAMA_BUF_RSRC(ptr, bytes) lama_make_buf(ptr, bytes)
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0)
+#define LAMA_BUF_LOAD_B64(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0)
 #define LAMA_BUF_LOAD_B16(rsrc, voff, soff) __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, soff, 0)     // 16-bit element, zero-extended
 #define LAMA_BUF_STORE_B16(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(val), rsrc, voff, soff, 0)
 // out-of-range buffer stores are dropped: a predicated store without a branch
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b32(val, rsrc, voff, soff, 0)
+#define LAMA_BUF_STORE_B64(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b64(val, rsrc, voff, soff, 0)     // val: 2 x u32 vector
 #define LAMA_BUF_STORE_B128(rsrc, val, voff, soff) __builtin_amdgcn_raw_buffer_store_b128(val, rsrc, voff, soff, 0)   // val: 4 x u32 vector
 #define LAMA_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #define LAMA_CLOCK() ((long long)wall_clock64())   // 100 MHz constant counter (timeline traces of the profiling tools)
@@ -103,6 +105,13 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
         __builtin_amdgcn_wave_barrier();                              \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        \
     } while (0)
+#endif
+
+// keep a value in ACCUMULATION registers from here on (gfx90a+: one unified 512-entry file per lane at one wave per SIMD, but VALU / memory
+// instructions address the 256 architectural VGPRs only, MFMA operands either half): an empty asm with an "a" constraint.
+// (tests/hipemu: no-op.)
+#ifndef LAMA_PIN_AGPR
+#define LAMA_PIN_AGPR(x) asm volatile("" : "+a"(x))
 #endif
 
 // make a per-lane integer opaque to the optimiser at this point of the program (pins the loads that depend on it behind the

@@ -311,6 +311,20 @@ static inline void hipemu_buf_store_b128(lama_buf_t r, hipemu_u32x4 v, unsigned 
     if (o + 16 <= r.n) memcpy(const_cast<char*>(r.p) + o, &v, 16);
 }
 #define LAMA_BUF_STORE_B128(rsrc, val, voff, soff) hipemu_buf_store_b128(rsrc, val, voff, soff)
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_u32x2 hipemu_buf_load_b64(lama_buf_t r, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    hipemu_u32x2 v = {0, 0};
+    if (o + 8 <= r.n) memcpy(&v, r.p + o, 8);
+    return v;
+}
+static inline void hipemu_buf_store_b64(lama_buf_t r, hipemu_u32x2 v, unsigned voff, unsigned soff) {
+    unsigned long long o = (unsigned long long)voff + soff;
+    if (o + 8 <= r.n) memcpy(const_cast<char*>(r.p) + o, &v, 8);
+}
+#define LAMA_BUF_LOAD_B64(rsrc, voff, soff) hipemu_buf_load_b64(rsrc, voff, soff)
+#define LAMA_PIN_AGPR(x) ((void)0)
+#define LAMA_BUF_STORE_B64(rsrc, val, voff, soff) hipemu_buf_store_b64(rsrc, val, voff, soff)
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) hipemu_buf_store_b32(rsrc, val, voff, soff)
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)

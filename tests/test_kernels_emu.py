@@ -89,6 +89,14 @@ CONV_CASES = [
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=31, act=1, bias=True, resid=False, scale=True, wl_slots=1),     # 14 tiles: one round + 6 whole left-overs
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=4, W=32, act=1, bias=True, resid=True, scale=True, wl=2),            # whole tiles only: 16-byte stores through the wave's LDS transpose
     dict(cin=192, cout=192, k=1, stride=1, pad=0, H=8, W=16, act=2, bias=True, resid=False, scale=False, wl_slots=1),   # ... two row groups, 8 tiles on 8 waves
+    # ... and over 64-pixel super-tiles of two interleaved MFMA tiles (gemm1x1_w4_kernel; LAMA_GEMM_W4=2 forces it at any launch size, LAMA_GEMM_W4_SLOTS
+    # caps the workgroups per row group): super-tiles across the image boundary, groups past the batch, several rounds, the split tail, K = 192
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=True, scale=True, w4_slots=0),        # 532 pixels = 8.3 super-tiles, one round
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=True, scale=True, w4_slots=4),        # two rounds + the 9th super-tile as 2 single tiles
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=0, bias=False, resid=False, scale=False, w4_slots=2),     # four rounds + the split tail on both slots
+    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=6, W=40, act=2, bias=True, resid=False, scale=False, w4_slots=3),     # K = 192, two row groups, two rounds + 2 whole left-overs, sigmoid
+    dict(cin=192, cout=96, k=1, stride=1, pad=0, H=6, W=40, act=1, bias=True, resid=True, scale=True, w4_slots=1),        # K = 192, eight rounds on one workgroup
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=4, W=33, act=1, bias=True, resid=True, scale=True, w4_slots=2),       # four row groups, 264 pixels
     # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
     dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True),
     dict(cin=3, cout=40, k=7, stride=1, pad=3, H=6, W=20, act=0, bias=False, resid=False, scale=False),
@@ -105,7 +113,7 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
     if 'ct' in case:
@@ -114,6 +122,10 @@ def test_conv2d_emulated(case, prec, monkeypatch):
         monkeypatch.setenv('LAMA_CT_GRID', str(case['ct_grid']))
     if 'wl' in case:
         monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
+    if 'w4_slots' in case:
+        monkeypatch.setenv('LAMA_GEMM_WL', '0')
+        monkeypatch.setenv('LAMA_GEMM_W4', '2')
+        monkeypatch.setenv('LAMA_GEMM_W4_SLOTS', str(case['w4_slots']))
     if 'wl_slots' in case:
         monkeypatch.setenv('LAMA_GEMM_WL_SLOTS', str(case['wl_slots']))
     if case.get('geo'):
