@@ -90,11 +90,11 @@ CONV_CASES = [
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=4, W=32, act=1, bias=True, resid=True, scale=True, wl=2),            # whole tiles only: 16-byte stores through the wave's LDS transpose
     dict(cin=192, cout=192, k=1, stride=1, pad=0, H=8, W=16, act=2, bias=True, resid=False, scale=False, wl_slots=1),   # ... two row groups, 8 tiles on 8 waves
     # ... and over 64-pixel super-tiles of two interleaved MFMA tiles (gemm1x1_w4_kernel; LAMA_GEMM_W4=2 forces it at any launch size, LAMA_GEMM_W4_SLOTS
-    # caps the workgroups per row group): super-tiles across the image boundary, groups past the batch, several rounds, the split tail, K = 192
+    # caps the workgroups per row group): super-tiles across the image boundary, groups past the batch, several rounds, left-over super-tiles, K = 192
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=True, scale=True, w4_slots=0),        # 532 pixels = 8.3 super-tiles, one round
-    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=True, scale=True, w4_slots=4),        # two rounds + the 9th super-tile as 2 single tiles
-    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=0, bias=False, resid=False, scale=False, w4_slots=2),     # four rounds + the split tail on both slots
-    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=6, W=40, act=2, bias=True, resid=False, scale=False, w4_slots=3),     # K = 192, two row groups, two rounds + 2 whole left-overs, sigmoid
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=True, scale=True, w4_slots=4),        # two rounds + one left-over super-tile
+    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=0, bias=False, resid=False, scale=False, w4_slots=2),     # four rounds + one left-over
+    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=6, W=40, act=1, bias=True, resid=False, scale=False, w4_slots=3),     # K = 192, two row groups, two rounds + 2 whole left-overs
     dict(cin=192, cout=96, k=1, stride=1, pad=0, H=6, W=40, act=1, bias=True, resid=True, scale=True, w4_slots=1),        # K = 192, eight rounds on one workgroup
     dict(cin=384, cout=384, k=1, stride=1, pad=0, H=4, W=33, act=1, bias=True, resid=True, scale=True, w4_slots=2),       # four row groups, 264 pixels
     # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
