@@ -579,7 +579,12 @@ __device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, i
     __syncthreads();
 }
 
-template <bool TR = false, bool HF = false>
+// SPLIT (fp32 input only; lama_fourier_unit_fwd): the spectrum leaves PRE-SPLIT for the 3-term-split GEMM that consumes it (gemm1x1_w4_kernel<PRE>,
+// conv_ws_dev.inc) instead of as fp32 Re / Im planes: every complex value becomes one dword of hi parts (half(Re), half(Im)) and one dword of
+// lo parts (half(Re - hi), half(Im - hi)) -- 1 = fp16, 2 = bf16 halves, exactly the split the GEMM kernels apply to fp32 operands -- in two
+// planes (p.spec = hi, p.y = lo) of [B][C / 4][h * wf] 16-byte units = the MFMA B fragment (8 consecutive channels of the interleaved Re / Im
+// spectrum = 4 complex channels) of one spectrum point.  Same bytes as the fp32 spectrum; the GEMM needs no VALU instruction for its operands.
+template <bool TR = false, bool HF = false, int SPLIT = 0>
 __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
     FFT_IO(p);
     if (p.prio) __builtin_amdgcn_s_setprio(3);
@@ -587,7 +592,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* P = tww + w;                       // h == w: one twiddle table
     const int tid = threadIdx.x;
-    const int plane = blockIdx.x;
+    // (SPLIT: neighbouring planes -- the four channels of a 16-byte unit -- on one XCD, so that their partial lines merge in its L2)
+    const int plane = SPLIT != 0 ? lama_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. row pairs straight from HBM (requested before the twiddles are computed): P[f][n] = (x[2f][n], x[2f+1][n])
     float4 ra[2], rb[2];
@@ -645,6 +651,37 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
     // 4. column FFTs over columns 0..31 (column 0 packs DC + Nyquist): FFT f = column, element stride wf, FFT stride 1
     ip_pass<false>(P, tww, 1, wf, 1);
     ip_pass<false>(P, tww, 8, wf, 1);
+    if constexpr (SPLIT != 0) {
+        // 5 + 6. one spectrum point per lane and pass (consecutive lanes = consecutive points = consecutive 16-byte units: a wave's store
+        // covers 1 KB, the four channels of a unit complete its lines from neighbouring workgroups of the same XCD)
+        const int per_plane = h * wf;
+        unsigned* const dhi = reinterpret_cast<unsigned*>(p.spec) + (long long)b * p.spec_bstride + ((long long)(c >> 2) * per_plane) * 4 + (c & 3);
+        unsigned* const dlo = reinterpret_cast<unsigned*>(p.y) + (long long)b * p.spec_bstride + ((long long)(c >> 2) * per_plane) * 4 + (c & 3);
+        for (int i = tid; i < per_plane; i += LAMA_NTHREADS) {
+            const int k = i / wf, col = i - k * wf;
+            float2 v = P[col == wh ? k * wf : i];
+            if (col == 0 || col == wh) {
+                const float2 cc = P[k * wf], cm = P[((h - k) & (h - 1)) * wf];
+                v = col == 0 ? make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y)) : make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
+            }
+            const float re = v.x * p.scale, im = v.y * p.scale;
+            unsigned hi, lo;
+            if constexpr (SPLIT == 1) {
+                const _Float16 hr = (_Float16)re, hi_ = (_Float16)im;
+                const _Float16 lr = (_Float16)(re - (float)hr), li = (_Float16)(im - (float)hi_);
+                hi = (unsigned)__builtin_bit_cast(unsigned short, hr) | ((unsigned)__builtin_bit_cast(unsigned short, hi_) << 16);
+                lo = (unsigned)__builtin_bit_cast(unsigned short, lr) | ((unsigned)__builtin_bit_cast(unsigned short, li) << 16);
+            } else {
+                const __bf16 hr = (__bf16)re, hi_ = (__bf16)im;
+                const __bf16 lr = (__bf16)(re - (float)hr), li = (__bf16)(im - (float)hi_);
+                hi = (unsigned)__builtin_bit_cast(unsigned short, hr) | ((unsigned)__builtin_bit_cast(unsigned short, hi_) << 16);
+                lo = (unsigned)__builtin_bit_cast(unsigned short, lr) | ((unsigned)__builtin_bit_cast(unsigned short, li) << 16);
+            }
+            dhi[(long long)i * 4] = hi;
+            dlo[(long long)i * 4] = lo;
+        }
+        return;
+    }
     // 5 + 6. float4 stores of the Re / Im planes; DC (col 0) and Nyquist (col 32) untangled from the packed column 0 on the fly
     {
         const int per_plane = h * wf;
@@ -1468,6 +1505,32 @@ extern "C" size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, 
         if (hf) hipLaunchKernelGGL((name<FFT_UNPAREN targs, true>), grid, blk, lds, st, __VA_ARGS__);   \
         else hipLaunchKernelGGL((name<FFT_UNPAREN targs, false>), grid, blk, lds, st, __VA_ARGS__);     \
     } while (0)
+
+// internal (lama_fourier_unit_fwd): 64 x 64 fp32 planes -> the pre-split spectrum (rfft2_ip64_kernel<SPLIT>); hi / lo: B * C * 64 * 33 * 8
+// bytes each; mode 1 = fp16 halves (LAMA_PREC_F16X3), 2 = bf16 (LAMA_PREC_BF16X3).  LAMA_ERR_UNSUPPORTED when the shape does not qualify.
+int lama_rfft2_split64(void* stream, const lama_tensor* x, void* hi, void* lo, int32_t batch, int mode) {
+    if (!x || !x->ptr || !hi || !lo || batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (x->dtype != LAMA_DT_F32 || x->H != 64 || x->W != 64 || x->C % 4 != 0 || (mode != 1 && mode != 2) || !fft_inplace()) return LAMA_ERR_UNSUPPORTED;
+    if ((((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4)) & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 15)) return LAMA_ERR_UNSUPPORTED;
+    if (x->batch_stride < (int64_t)x->C * 64 * 64) return LAMA_ERR_BAD_ARG;
+    FftParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x->ptr;
+    p.x_bstride = x->batch_stride;
+    p.spec = hi;
+    p.y = lo;
+    p.spec_bstride = (long long)x->C * 64 * IP_WF;       // dwords per image and plane: C / 4 units x 2112 points x 4
+    p.C = x->C; p.h = 64; p.w = 64; p.wf = IP_WF;
+    p.nplanes = batch * x->C;
+    p.scale = 1.0f / 64.0f;
+    p.prio = lama_side_prio();
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(IP_N + IP_BUF) * sizeof(float2);
+    if (mode == 1) hipLaunchKernelGGL((rfft2_ip64_kernel<false, false, 1>), dim3(p.nplanes), dim3(LAMA_NTHREADS), lds, st, p);
+    else hipLaunchKernelGGL((rfft2_ip64_kernel<false, false, 2>), dim3(p.nplanes), dim3(LAMA_NTHREADS), lds, st, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
 
 extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch,
                               void* workspace, size_t workspace_bytes) {

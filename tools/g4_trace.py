@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of the super-tile pointwise GEMM (gemm1x1_w4_kernel, LAMA_GW_TRACE; profiling build).
 usage: g4_trace.py [conv1|fuconv] [nrot]   (fuconv only: the traced instantiation is K = 384 without residual)
-stamps (100 MHz): 0 start, 1 weights + first chunks requested, 2 + 2u / 3 + 2u K loop / epilogue of super-tile u (u < 5), 12 / 13 tail tile, 15 end"""
+stamps (100 MHz): 0 start, 1 weights + first ring requested, 2 + u = K loop + exchange writes of super-tile u done (u < 10), 14 last epilogue done, 15 end"""
 import os
 import sys
 
@@ -41,16 +41,13 @@ t0 = int(t[:, 0].min())
 rel = (t.double() - t0) / 100.0
 print(f'{name} nrot={nrot}: {t.shape[0]} workgroups, event time {a.elapsed_time(b) * 1e3:.1f} us; us relative to the first start')
 print(f'start: median {rel[:, 0].median():.2f} max {rel[:, 0].max():.2f};  end: median {rel[:, 15].median():.2f} last {rel[:, 15].max():.2f}')
-print(f'prologue (weights + first ring requested): median {(rel[:, 1] - rel[:, 0]).median():.2f}')
+print(f'prologue (first ring + weights requested): median {(rel[:, 1] - rel[:, 0]).median():.2f}')
 prev = rel[:, 1]
-for u in range(5):
-    ok = t[:, 2 + 2 * u] > 0
+for u in range(10):
+    ok = t[:, 2 + u] > 0
     if not bool(ok.any()):
         break
-    k, e = rel[:, 2 + 2 * u], rel[:, 3 + 2 * u]
-    print(f'  super-tile {u}: {int(ok.sum())} workgroups, K loop median {(k - prev)[ok].median():.2f} p90 {(k - prev)[ok].quantile(0.9):.2f} | '
-          f'epilogue median {(e - k)[ok].median():.2f} p90 {(e - k)[ok].quantile(0.9):.2f} | done at median {e[ok].median():.2f}')
-    prev = e
-ok = t[:, 12] > 0
-if bool(ok.any()):
-    print(f'  tail tile: {int(ok.sum())} workgroups, K loop + its prologue median {(rel[:, 12] - prev)[ok].median():.2f} | epilogue {(rel[:, 13] - rel[:, 12])[ok].median():.2f} | done at {rel[:, 13][ok].median():.2f}')
+    k = rel[:, 2 + u]
+    print(f'  super-tile {u}: {int(ok.sum())} workgroups, K loop + exchange writes median {(k - prev)[ok].median():.2f} p90 {(k - prev)[ok].quantile(0.9):.2f} | done at median {k[ok].median():.2f} max {k[ok].max():.2f}')
+    prev = k
+print(f'last epilogue (bare): median {(rel[:, 14] - prev).median():.2f};  end: median {rel[:, 15].median():.2f} last {rel[:, 15].max():.2f}')
