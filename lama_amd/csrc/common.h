@@ -134,6 +134,7 @@ LAMA_CB_DECL(_f16)
 // the FourierUnit's pre-split spectrum (internal: lama_fourier_unit_fwd): rfft2 of 64 x 64 planes straight into the (hi, lo) B-fragment planes
 // (fft.hip) and the pointwise GEMM that reads them (conv_ws_dev.inc, gemm1x1_w4_kernel<PRE>); LAMA_ERR_UNSUPPORTED = take the fp32 route
 int lama_rfft2_split64(void* stream, const lama_tensor* x, void* hi, void* lo, int32_t batch, int mode);
+int lama_irfft2_quad64(void* stream, const void* specq, const lama_tensor* resid, const lama_tensor* y, int32_t batch);
 #define LAMA_GS_DECL(sfx)                                                                                                          \
     int lama_cb_gemm_split_fwd##sfx(hipStream_t stream, const void* hi, const void* lo, int cin, int HW, const void* w_packed,       \
                                     const float* bias, int act, const lama_tensor* y, int batch, unsigned* range_flag);

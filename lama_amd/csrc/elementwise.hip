@@ -271,7 +271,7 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
                 rc = f16 ? lama_cb_gemm_split_fwd_f16x3((hipStream_t)stream, hi, lo, 2 * C, HW, w_packed, bias, LAMA_ACT_RELU, &s2, batch, range_flag)
                          : lama_cb_gemm_split_fwd_bf16x3((hipStream_t)stream, hi, lo, 2 * C, HW, w_packed, bias, LAMA_ACT_RELU, &s2, batch, range_flag);
                 if (rc) return rc;
-                return lama_irfft2_fwd(stream, &s2, add_input ? x : nullptr, y, batch, fws, fws_bytes);
+                return lama_irfft2_quad64(stream, s2.ptr, add_input ? x : nullptr, y, batch);     // the GEMM's output is row-quad-minor
             }
             if (rc != LAMA_ERR_UNSUPPORTED) return rc;
         }
