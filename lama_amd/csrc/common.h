@@ -131,16 +131,6 @@ LAMA_CB_DECL(_bf16x3)
 LAMA_CB_DECL(_f16x3)
 LAMA_CB_DECL(_f16)
 #undef LAMA_CB_DECL
-// the FourierUnit's pre-split spectrum (internal: lama_fourier_unit_fwd): rfft2 of 64 x 64 planes straight into the (hi, lo) B-fragment planes
-// (fft.hip) and the pointwise GEMM that reads them (conv_ws_dev.inc, gemm1x1_w4_kernel<PRE>); LAMA_ERR_UNSUPPORTED = take the fp32 route
-int lama_rfft2_split64(void* stream, const lama_tensor* x, void* hi, void* lo, int32_t batch, int mode);
-int lama_irfft2_quad64(void* stream, const void* specq, const lama_tensor* resid, const lama_tensor* y, int32_t batch);
-#define LAMA_GS_DECL(sfx)                                                                                                          \
-    int lama_cb_gemm_split_fwd##sfx(hipStream_t stream, const void* hi, const void* lo, int cin, int HW, const void* w_packed,       \
-                                    const float* bias, int act, const lama_tensor* y, int batch, unsigned* range_flag);
-LAMA_GS_DECL(_bf16x3)
-LAMA_GS_DECL(_f16x3)
-#undef LAMA_GS_DECL
 // Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect convolution (wino_dev.inc), reached through lama_winograd_* with LAMA_PREC_BF16X3 / F16X3
 #define LAMA_WG_DECL(sfx)                                                                                                          \
     int64_t lama_cb_wino_packed_weight_bytes##sfx(int cout, int cin);                                                               \

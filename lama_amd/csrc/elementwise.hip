@@ -255,27 +255,6 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
     lama_tensor s2 = {ws + spec_bytes, (int64_t)2 * C * h * wf, 2 * C, h, wf, x->dtype};
     void* fws = ws + 2 * spec_bytes;
     size_t fws_bytes = workspace_bytes - 2 * spec_bytes;
-    // 64 x 64 fp32 planes on the 3-term-split precisions: the spectrum goes to the GEMM PRE-SPLIT in MFMA B-fragment order (the two halves of
-    // the first spectrum buffer are its hi and lo planes; fft.hip rfft2_ip64_kernel<SPLIT>, conv_ws_dev.inc gemm1x1_w4_kernel<PRE>): no
-    // operand VALU work and 16-byte loads in the GEMM.  Whether the shape qualifies is asked before anything is launched.
-    if (x->dtype == LAMA_DT_F32 && h == 64 && w == 64 && (precision == LAMA_PREC_F16X3 || precision == LAMA_PREC_BF16X3)) {
-        const bool f16 = precision == LAMA_PREC_F16X3;
-        const int HW = h * wf;
-        const int ok = f16 ? lama_cb_gemm_split_fwd_f16x3(nullptr, nullptr, nullptr, 2 * C, HW, w_packed, bias, LAMA_ACT_RELU, &s2, batch, nullptr)
-                           : lama_cb_gemm_split_fwd_bf16x3(nullptr, nullptr, nullptr, 2 * C, HW, w_packed, bias, LAMA_ACT_RELU, &s2, batch, nullptr);
-        if (ok == LAMA_OK) {
-            char* const hi = ws;
-            char* const lo = ws + (size_t)batch * C * HW * 4;        // each plane: B * C points-planes x 4 bytes = half of the fp32 spectrum
-            int rc = lama_rfft2_split64(stream, x, hi, lo, batch, f16 ? 1 : 2);
-            if (rc == LAMA_OK) {
-                rc = f16 ? lama_cb_gemm_split_fwd_f16x3((hipStream_t)stream, hi, lo, 2 * C, HW, w_packed, bias, LAMA_ACT_RELU, &s2, batch, range_flag)
-                         : lama_cb_gemm_split_fwd_bf16x3((hipStream_t)stream, hi, lo, 2 * C, HW, w_packed, bias, LAMA_ACT_RELU, &s2, batch, range_flag);
-                if (rc) return rc;
-                return lama_irfft2_quad64(stream, s2.ptr, add_input ? x : nullptr, y, batch);     // the GEMM's output is row-quad-minor
-            }
-            if (rc != LAMA_ERR_UNSUPPORTED) return rc;
-        }
-    }
     int rc = lama_rfft2_fwd(stream, x, &s1, batch, fws, fws_bytes);
     if (rc) return rc;
     lama_conv2d_args a;

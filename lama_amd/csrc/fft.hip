@@ -560,7 +560,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_lds_kernel(FftParams p) 
 // one radix-8 Stockham pass over 32 FFTs of length 64, in place: thread = (FFT f = tid % 32, butterfly j = tid / 32)
 template <bool INV>
 __device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, int estride, int fstride) {
-    const int tid = threadIdx.x & (LAMA_NTHREADS - 1);   // (the SPLIT forward kernel runs four 256-thread groups, one plane each)
+    const int tid = threadIdx.x;
     const int f = tid & 31, j = tid >> 5;        // j in 0..7 (N / R = 8 butterflies per FFT)
     const int k = j & (Ns - 1);
     float2* s = buf + f * fstride;
@@ -579,24 +579,15 @@ __device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, i
     __syncthreads();
 }
 
-// SPLIT (fp32 input only; lama_fourier_unit_fwd): the spectrum leaves PRE-SPLIT for the 3-term-split GEMM that consumes it (gemm1x1_w4_kernel<PRE>,
-// conv_ws_dev.inc) instead of as fp32 Re / Im planes: every complex value becomes one dword of hi parts (half(Re), half(Im)) and one dword of
-// lo parts (half(Re - hi), half(Im - hi)) -- 1 = fp16, 2 = bf16 halves, exactly the split the GEMM kernels apply to fp32 operands -- in two
-// planes (p.spec = hi, p.y = lo) of [B][C / 4][h * wf] 16-byte units = the MFMA B fragment (8 consecutive channels of the interleaved Re / Im
-// spectrum = 4 complex channels) of one spectrum point.  Same bytes as the fp32 spectrum; the GEMM needs no VALU instruction for its operands.
-// One lane has one channel's 4 bytes of a unit, so a SPLIT workgroup is FOUR 256-thread groups = the four planes of a unit side by side (68 KB
-// of LDS, every barrier spans the 1024 threads, which run the same phases): the groups leave their (hi, lo) dwords in LDS and the workgroup
-// stores whole 16-byte units (4 stores per thread; 4-byte stores at a 16-byte pitch from one plane per workgroup cost 2.5 us: 18 store
-// instructions per thread).
-template <bool TR = false, bool HF = false, int SPLIT = 0>
-__global__ __launch_bounds__(LAMA_NTHREADS * (SPLIT != 0 ? 4 : 1)) void rfft2_ip64_kernel(FftParams p) {
+template <bool TR = false, bool HF = false>
+__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
     FFT_IO(p);
     if (p.prio) __builtin_amdgcn_s_setprio(3);
     constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
     float2* tww = reinterpret_cast<float2*>(lama_smem);
-    const int tid = threadIdx.x & (LAMA_NTHREADS - 1), grp = threadIdx.x / LAMA_NTHREADS;
-    float2* P = tww + w + grp * IP_BUF;        // h == w: one twiddle table (shared by the groups)
-    const int plane = SPLIT != 0 ? blockIdx.x * 4 + grp : blockIdx.x;
+    float2* P = tww + w;                       // h == w: one twiddle table
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. row pairs straight from HBM (requested before the twiddles are computed): P[f][n] = (x[2f][n], x[2f+1][n])
     float4 ra[2], rb[2];
@@ -654,55 +645,6 @@ __global__ __launch_bounds__(LAMA_NTHREADS * (SPLIT != 0 ? 4 : 1)) void rfft2_ip
     // 4. column FFTs over columns 0..31 (column 0 packs DC + Nyquist): FFT f = column, element stride wf, FFT stride 1
     ip_pass<false>(P, tww, 1, wf, 1);
     ip_pass<false>(P, tww, 8, wf, 1);
-    if constexpr (SPLIT != 0) {
-        // 5 + 6. every group splits its plane's points into (hi, lo) dwords, leaves them in its own buffer, and the workgroup stores 16-byte
-        // units: lane = point, the four channels of the unit from the four buffers
-        constexpr int per_plane = h * wf, NIT = (per_plane + LAMA_NTHREADS - 1) / LAMA_NTHREADS;
-        unsigned vh[NIT], vl[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * LAMA_NTHREADS;
-            vh[it] = vl[it] = 0u;
-            if (i < per_plane) {
-                const int k = i / wf, col = i - k * wf;
-                float2 v = P[col == wh ? k * wf : i];
-                if (col == 0 || col == wh) {
-                    const float2 cc = P[k * wf], cm = P[((h - k) & (h - 1)) * wf];
-                    v = col == 0 ? make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y)) : make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
-                }
-                const float re = v.x * p.scale, im = v.y * p.scale;
-                if constexpr (SPLIT == 1) {
-                    const _Float16 hr = (_Float16)re, hi_ = (_Float16)im;
-                    const _Float16 lr = (_Float16)(re - (float)hr), li = (_Float16)(im - (float)hi_);
-                    vh[it] = (unsigned)__builtin_bit_cast(unsigned short, hr) | ((unsigned)__builtin_bit_cast(unsigned short, hi_) << 16);
-                    vl[it] = (unsigned)__builtin_bit_cast(unsigned short, lr) | ((unsigned)__builtin_bit_cast(unsigned short, li) << 16);
-                } else {
-                    const __bf16 hr = (__bf16)re, hi_ = (__bf16)im;
-                    const __bf16 lr = (__bf16)(re - (float)hr), li = (__bf16)(im - (float)hi_);
-                    vh[it] = (unsigned)__builtin_bit_cast(unsigned short, hr) | ((unsigned)__builtin_bit_cast(unsigned short, hi_) << 16);
-                    vl[it] = (unsigned)__builtin_bit_cast(unsigned short, lr) | ((unsigned)__builtin_bit_cast(unsigned short, li) << 16);
-                }
-            }
-        }
-        __syncthreads();
-        uint2* const Pu = reinterpret_cast<uint2*>(P);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * LAMA_NTHREADS;
-            if (i < per_plane) Pu[i] = make_uint2(vh[it], vl[it]);
-        }
-        __syncthreads();
-        const int plane0 = blockIdx.x * 4, b0 = plane0 / p.C, c0 = plane0 - b0 * p.C;
-        const unsigned* const U = reinterpret_cast<const unsigned*>(tww + w);            // group g's point i: U[(g * IP_BUF + i) * 2 + part]
-        uint4* const dhi = reinterpret_cast<uint4*>(reinterpret_cast<unsigned*>(p.spec) + (long long)b0 * p.spec_bstride + (long long)(c0 >> 2) * per_plane * 4);
-        uint4* const dlo = reinterpret_cast<uint4*>(reinterpret_cast<unsigned*>(p.y) + (long long)b0 * p.spec_bstride + (long long)(c0 >> 2) * per_plane * 4);
-        for (int j = threadIdx.x; j < 2 * per_plane; j += 4 * LAMA_NTHREADS) {
-            const int part = j >= per_plane ? 1 : 0, i = j - part * per_plane;
-            const uint4 u = make_uint4(U[(0 * IP_BUF + i) * 2 + part], U[(1 * IP_BUF + i) * 2 + part], U[(2 * IP_BUF + i) * 2 + part], U[(3 * IP_BUF + i) * 2 + part]);
-            (part ? dlo : dhi)[i] = u;
-        }
-        return;
-    }
     // 5 + 6. float4 stores of the Re / Im planes; DC (col 0) and Nyquist (col 32) untangled from the packed column 0 on the fly
     {
         const int per_plane = h * wf;
@@ -727,9 +669,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS * (SPLIT != 0 ? 4 : 1)) void rfft2_ip
     }
 }
 
-// QIN (fp32 only; lama_fourier_unit_fwd): the spectrum arrives "row-quad-minor" as gemm1x1_w4_kernel<PRE> stores it -- [B][2C / 4][h * wf][4
-// channels] -- so a complex value (channels 2c, 2c + 1) is ONE 8-byte load at a 16-byte pitch.
-template <bool TR = false, bool HF = false, bool QIN = false>
+template <bool TR = false, bool HF = false>
 __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p) {
     FFT_IO(p);
     if (p.prio) __builtin_amdgcn_s_setprio(3);
@@ -738,21 +678,11 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* P = tww + w;
     const int tid = threadIdx.x;
-    // (QIN: the two planes of a quad on one XCD: they read the same lines)
-    const int plane = QIN ? lama_xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int plane = blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. the Re / Im planes (float4 loads, requested before the twiddles are computed) and the residual rows
     const auto sbase = ps + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
     float4 sre[3], sim[3];
-    float2 sq[QIN ? 9 : 1];
-    if constexpr (QIN) {
-        const float* const qb = reinterpret_cast<const float*>(p.spec) + (long long)b * p.spec_bstride + (long long)(c >> 1) * per_plane * 4 + (c & 1) * 2;
-#pragma unroll
-        for (int it = 0; it < 9; ++it) {
-            const int i = tid + it * LAMA_NTHREADS;
-            if (i < per_plane) sq[it] = *reinterpret_cast<const float2*>(qb + (long long)i * 4);
-        }
-    } else {
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         const int i4 = tid + it * LAMA_NTHREADS;
@@ -760,7 +690,6 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
             sre[it] = fft_ld4(sbase + i4 * 4);
             sim[it] = fft_ld4(sbase + per_plane + i4 * 4);
         }
-    }
     }
     float4 rxa[2], rxb[2];
     if (px) {
@@ -774,13 +703,6 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
         }
     }
     fft_init_twiddles<true>(tww, w);
-    if constexpr (QIN) {
-#pragma unroll
-        for (int it = 0; it < 9; ++it) {
-            const int i = tid + it * LAMA_NTHREADS;
-            if (i < per_plane) P[i] = sq[it];
-        }
-    } else {
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         const int i4 = tid + it * LAMA_NTHREADS;
@@ -791,7 +713,6 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void irfft2_ip64_kernel(FftParams p)
             d[2] = make_float2(sre[it].z, sim[it].z);
             d[3] = make_float2(sre[it].w, sim[it].w);
         }
-    }
     }
     __syncthreads();
     // 2. Hermitian-symmetrise columns 0 and w/2 along h and pack them into column 0 (see irfft2_lds_kernel)
@@ -1547,56 +1468,6 @@ extern "C" size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, 
         if (hf) hipLaunchKernelGGL((name<FFT_UNPAREN targs, true>), grid, blk, lds, st, __VA_ARGS__);   \
         else hipLaunchKernelGGL((name<FFT_UNPAREN targs, false>), grid, blk, lds, st, __VA_ARGS__);     \
     } while (0)
-
-// internal (lama_fourier_unit_fwd): 64 x 64 fp32 planes -> the pre-split spectrum (rfft2_ip64_kernel<SPLIT>); hi / lo: B * C * 64 * 33 * 8
-// bytes each; mode 1 = fp16 halves (LAMA_PREC_F16X3), 2 = bf16 (LAMA_PREC_BF16X3).  LAMA_ERR_UNSUPPORTED when the shape does not qualify.
-int lama_rfft2_split64(void* stream, const lama_tensor* x, void* hi, void* lo, int32_t batch, int mode) {
-    if (!x || !x->ptr || !hi || !lo || batch <= 0) return LAMA_ERR_BAD_ARG;
-    if (x->dtype != LAMA_DT_F32 || x->H != 64 || x->W != 64 || x->C % 4 != 0 || (mode != 1 && mode != 2) || !fft_inplace()) return LAMA_ERR_UNSUPPORTED;
-    if ((((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4)) & 15) || (((uintptr_t)hi | (uintptr_t)lo) & 15)) return LAMA_ERR_UNSUPPORTED;
-    if (x->batch_stride < (int64_t)x->C * 64 * 64) return LAMA_ERR_BAD_ARG;
-    FftParams p;
-    memset(&p, 0, sizeof(p));
-    p.x = x->ptr;
-    p.x_bstride = x->batch_stride;
-    p.spec = hi;
-    p.y = lo;
-    p.spec_bstride = (long long)x->C * 64 * IP_WF;       // dwords per image and plane: C / 4 units x 2112 points x 4
-    p.C = x->C; p.h = 64; p.w = 64; p.wf = IP_WF;
-    p.nplanes = batch * x->C;
-    p.scale = 1.0f / 64.0f;
-    p.prio = lama_side_prio();
-    hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)(IP_N + 4 * IP_BUF) * sizeof(float2);     // four planes per workgroup
-    if (mode == 1) hipLaunchKernelGGL((rfft2_ip64_kernel<false, false, 1>), dim3(p.nplanes / 4), dim3(4 * LAMA_NTHREADS), lds, st, p);
-    else hipLaunchKernelGGL((rfft2_ip64_kernel<false, false, 2>), dim3(p.nplanes / 4), dim3(4 * LAMA_NTHREADS), lds, st, p);
-    LAMA_CHECK_LAUNCH();
-    return LAMA_OK;
-}
-
-// internal (lama_fourier_unit_fwd): irfft2 of 64 x 64 planes from the row-quad-minor spectrum [B][2C / 4][64 * 33][4] (+ residual)
-int lama_irfft2_quad64(void* stream, const void* specq, const lama_tensor* resid, const lama_tensor* y, int32_t batch) {
-    if (!specq || !y || !y->ptr || batch <= 0) return LAMA_ERR_BAD_ARG;
-    if (y->dtype != LAMA_DT_F32 || y->H != 64 || y->W != 64 || y->C % 2 != 0 || !fft_inplace()) return LAMA_ERR_UNSUPPORTED;
-    if (resid && (resid->dtype != LAMA_DT_F32 || resid->C != y->C || resid->H != 64 || resid->W != 64)) return LAMA_ERR_BAD_ARG;
-    if ((((uintptr_t)y->ptr | (uintptr_t)(y->batch_stride * 4) | (uintptr_t)specq) & 15)) return LAMA_ERR_UNSUPPORTED;
-    if (resid && (((uintptr_t)resid->ptr | (uintptr_t)(resid->batch_stride * 4)) & 15)) return LAMA_ERR_UNSUPPORTED;
-    FftParams p;
-    memset(&p, 0, sizeof(p));
-    p.x = resid ? resid->ptr : nullptr;
-    p.x_bstride = resid ? resid->batch_stride : 0;
-    p.spec = const_cast<void*>(specq);
-    p.spec_bstride = (long long)2 * y->C * 64 * IP_WF;
-    p.y = y->ptr;
-    p.y_bstride = y->batch_stride;
-    p.C = y->C; p.h = 64; p.w = 64; p.wf = IP_WF;
-    p.nplanes = batch * y->C;
-    p.scale = 1.0f / 64.0f;
-    p.prio = lama_side_prio();
-    hipLaunchKernelGGL((irfft2_ip64_kernel<false, false, true>), dim3(p.nplanes), dim3(LAMA_NTHREADS), (size_t)(IP_N + IP_BUF) * sizeof(float2), (hipStream_t)stream, p);
-    LAMA_CHECK_LAUNCH();
-    return LAMA_OK;
-}
 
 extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch,
                               void* workspace, size_t workspace_bytes) {

@@ -1,8 +1,6 @@
 """CPU tests of the HIP kernel SOURCES through the host SIMT emulator (tests/hipemu): index math, LDS
 layouts, MFMA fragment maps, barrier placement and the C-ABI argument handling, checked against
 plain torch fp32 ops.  The same comparisons run on the real GPU in test_kernels_gpu.py."""
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -281,41 +279,6 @@ def test_fourier_unit_emulated():
         y = torch.zeros_like(x)
         lib.fourier_unit(L.view(x), wp, shift, L.view(y), B, True, ws)
         assert torch.allclose(y, x + ref, atol=1e-4, rtol=1e-4), float((y - x - ref).abs().max())
-
-
-@pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
-def test_fourier_unit_presplit_spectrum_emulated(prec):
-    """64 x 64 planes on the 3-term-split precisions: lama_fourier_unit_fwd hands the spectrum to the GEMM PRE-SPLIT in MFMA B-fragment order
-    (rfft2_ip64_kernel<SPLIT> -> gemm1x1_w4_kernel<PRE>; K = 192, two row groups, 33 super-tiles per image on a few slots)."""
-    from oracle import lama_oracle as O
-    lib = emu_lib()
-    g = torch.Generator().manual_seed(7)
-    B, Cn, h, w = 1, 96, 64, 64
-    x = torch.randn(B, Cn, h, w, generator=g)
-    sd = {'fu.conv_layer.weight': torch.randn(2 * Cn, 2 * Cn, 1, 1, generator=g) / (2 * Cn) ** 0.5,
-          'fu.bn.weight': torch.rand(2 * Cn, generator=g) + 0.5, 'fu.bn.bias': torch.randn(2 * Cn, generator=g) * 0.2,
-          'fu.bn.running_mean': torch.randn(2 * Cn, generator=g) * 0.1, 'fu.bn.running_var': torch.rand(2 * Cn, generator=g) + 0.5}
-    ref = O.fourier_unit(x, sd, 'fu')
-    scale = sd['fu.bn.weight'] / torch.sqrt(sd['fu.bn.running_var'] + 1e-5)
-    shift = sd['fu.bn.bias'] - sd['fu.bn.running_mean'] * scale
-    wp = lib.pack_conv_weight(sd['fu.conv_layer.weight'], scale, precision=prec)
-    ws = torch.zeros(lib.fourier_unit_workspace_bytes(B, Cn, h, w) // 4 + 1)
-    y = torch.zeros_like(x)
-    os.environ['LAMA_GEMM_W4_SLOTS'] = '5'          # 33 super-tiles on 5 workgroups per row group: six rounds + 3 left-overs
-    try:
-        lib.fourier_unit(L.view(x), wp, shift, L.view(y), B, True, ws, precision=prec)
-        y_split = y.clone()
-        os.environ['LAMA_FU_SPLIT'] = '0'            # the fp32-spectrum route on the same input
-        y.zero_()
-        lib.fourier_unit(L.view(x), wp, shift, L.view(y), B, True, ws, precision=prec)
-    finally:
-        os.environ.pop('LAMA_GEMM_W4_SLOTS', None)
-        os.environ.pop('LAMA_FU_SPLIT', None)
-    tol = 1e-4 if prec == L.PREC_F16X3 else 6e-4
-    assert float((y_split - x - ref).abs().max()) < tol, float((y_split - x - ref).abs().max())
-    # same split, same products, another summation order: the two routes agree far below the tolerance against the oracle
-    assert float((y_split - y).abs().max()) < 2e-5, float((y_split - y).abs().max())
-    assert not torch.equal(y_split, y)      # ... and the pre-split route really ran (another summation order, not the same launches)
 
 
 def test_elementwise_emulated():
