@@ -10,8 +10,8 @@ import sys
 KEYS = [   # (bench key, kernel-name substrings summed into it, note)
     ('conv3x3_cin512_cout128_64x64', ['wino_gemm_kernel', 'wino_out_kernel'], 'local 3x3 conv as Winograd F(2x2,3x3): wino_gemm_kernel + wino_out_kernel (kprobe wino)', 86250000),
     ('conv3x3_cin128_cout384_64x64+1x1_cin192', ['conv_wr_kernel_f16x3<9, 2, 1, 4, 12, 1'], 'global 3x3 conv + fused 1x1 over t + residual (kprobe convB)', 144530000),
-    ('conv1x1_cin384_cout192_64x64', ['gemm1x1_ws_kernel_f16x3<6, false, 1'], 'SpectralTransform.conv1 (kprobe conv1; same kernel name as the spectral GEMM: told apart by grid size)', 75500000),
-    ('conv1x1_cin384_cout384_64x33', ['gemm1x1_ws_kernel_f16x3<6, false, 1'], 'spectral 1x1 of the FourierUnit (kprobe fuconv)', 52500000),
+    ('conv1x1_cin384_cout192_64x64', ['gemm1x1_w4_kernel_f16x3<6, 2, false'], 'SpectralTransform.conv1 (kprobe conv1; same kernel name as the spectral GEMM: told apart by grid size)', 75500000),
+    ('conv1x1_cin384_cout384_64x33', ['gemm1x1_w4_kernel_f16x3<6, 2, false'], 'spectral 1x1 of the FourierUnit (kprobe fuconv)', 52500000),
     ('rfft2_192x64x64', ['void rfft2_ip64_kernel'], 'rfft2 of 8 x 192 planes of 64 x 64', 51200000),
     ('irfft2_192x64x64', ['void irfft2_ip64_kernel'], 'irfft2 + residual', 76400000),
 ]
