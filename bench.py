@@ -20,7 +20,7 @@ The JSON line also carries
                    `peak_sustained` is what THIS box sustains on random operands with nothing but MFMAs in flight (measured
                    live through the profiling build's lama_debug_mfma_peak: the part is power limited) and
                    `frac_of_sustained` prices the kernel against that.  `traffic` comes from the committed PMC passes
-                   (profiles/r02_pmc.json; a live bench run cannot host the profiler).
+                   (profiles/r03_pmc.json; a live bench run cannot host the profiler).
   roofline_ffc  -- the unit BASELINE.json names: FourierUnit forward (rfft2 -> spectral 1x1+BN+ReLU ->
                    irfft2 + residual), algorithmic bytes / time against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (CPU restatement of the reference, same torch-CPU primitives) timed on
