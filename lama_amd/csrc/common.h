@@ -119,6 +119,11 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #ifndef LAMA_OPAQUE
 #define LAMA_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
+// the same for a wave-uniform integer (scalar register): inside a loop it keeps the address arithmetic that depends on it INSIDE the loop
+// (hoisted out of a fully unrolled body, a hundred loop-invariant scalar offsets spill)
+#ifndef LAMA_OPAQUE_S
+#define LAMA_OPAQUE_S(x) asm volatile("" : "+s"(x))
+#endif
 
 // 3-term split convolution back ends (conv_split3.inc compiled as conv_bf16x3.hip / conv_f16x3.hip), reached through
 // lama_conv2d_* with LAMA_PREC_BF16X3 / LAMA_PREC_F16X3

@@ -9,6 +9,8 @@ os.environ.setdefault('LAMA_GEMM_WS', '2')
 os.environ.setdefault('LAMA_GEMM_WL', '2')
 os.environ.setdefault('LAMA_STEM_WS', '2')
 os.environ.setdefault('LAMA_HEAD_WS', '2')
+# ... and the 12-wave all-rows workgroup of the global branch (production takes it from 160 tiles on: conv_wreg_host.inc)
+os.environ.setdefault('LAMA_CW_G12', '2')
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, 'hipemu'))

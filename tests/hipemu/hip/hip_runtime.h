@@ -272,6 +272,7 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(V8 a, V8 b, hipemu_f32x
 #define LAMA_LDS_PTR(p) ((void*)(p))
 #define LAMA_KEEP_LIVE(x) ((void)(x))
 #define LAMA_OPAQUE(x) ((void)(x))
+#define LAMA_OPAQUE_S(x) ((void)(x))
 static inline void hipemu_global_load_lds(const void* g, void* l, int size) { memcpy((char*)l + hipemu::lane() * size, g, size); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hipemu_global_load_lds((const char*)(g) + (off), l, size)
 

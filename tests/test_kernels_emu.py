@@ -97,6 +97,13 @@ CONV_CASES = [
     dict(cin=192, cout=192, k=1, stride=1, pad=0, H=6, W=40, act=1, bias=True, resid=False, scale=False, w4_slots=3),     # K = 192, two row groups, two rounds + 2 whole left-overs
     dict(cin=192, cout=96, k=1, stride=1, pad=0, H=6, W=40, act=1, bias=True, resid=True, scale=True, w4_slots=1),        # K = 192, eight rounds on one workgroup
     dict(cin=384, cout=384, k=1, stride=1, pad=0, H=4, W=33, act=1, bias=True, resid=True, scale=True, w4_slots=2),       # four row groups, 264 pixels
+    # ... and with all of K in one wave (gemm1x1_wk_kernel, gemm_wk_dev.inc; LAMA_GEMM_WK=2 forces it at any launch size, LAMA_GEMM_WK_SLOTS caps the
+    # workgroups): 384 -> 384 only
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=4, W=33, act=1, bias=True, resid=False, scale=True, wk_slots=0),      # 264 pixels = 4.1 super-tiles, one round, ragged last one
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=4, W=33, act=1, bias=True, resid=False, scale=True, wk_slots=4),      # one round + 1 left-over = 24 units on four fifth waves
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=4, W=33, act=0, bias=False, resid=False, scale=False, wk_slots=2),    # left-over too big for the fifth waves: 3 / 2 rounds
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=20, W=40, act=1, bias=True, resid=False, scale=False, wk_slots=12),   # 25 super-tiles: two rounds + 24 units, two per fifth wave
+    dict(cin=384, cout=384, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=False, scale=True, wk_slots=8),      # HW = 266: an image boundary inside a super-tile
     # stem kernel (conv_stem_dev.inc): 7x7, cin <= 4, 33..64 output channels; ragged last segment, rows past M, image narrower than a segment
     dict(cin=4, cout=64, k=7, stride=1, pad=3, H=9, W=40, act=1, bias=True, resid=False, scale=True),
     dict(cin=3, cout=40, k=7, stride=1, pad=3, H=6, W=20, act=0, bias=False, resid=False, scale=False),
@@ -113,7 +120,7 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'wks%d' % c['wk_slots'] if 'wk_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
     if 'ct' in case:
@@ -126,6 +133,10 @@ def test_conv2d_emulated(case, prec, monkeypatch):
         monkeypatch.setenv('LAMA_GEMM_WL', '0')
         monkeypatch.setenv('LAMA_GEMM_W4', '2')
         monkeypatch.setenv('LAMA_GEMM_W4_SLOTS', str(case['w4_slots']))
+    if 'wk_slots' in case:
+        monkeypatch.setenv('LAMA_GEMM_WL', '0')
+        monkeypatch.setenv('LAMA_GEMM_WK', '2')
+        monkeypatch.setenv('LAMA_GEMM_WK_SLOTS', str(case['wk_slots']))
     if 'wl_slots' in case:
         monkeypatch.setenv('LAMA_GEMM_WL_SLOTS', str(case['wl_slots']))
     if case.get('geo'):

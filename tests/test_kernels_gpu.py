@@ -42,7 +42,7 @@ DEV = 'cuda'
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'wks%d' % c['wk_slots'] if 'wk_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d(anylib, case, prec, monkeypatch):
     lib = anylib
     if 'ct' in case:
@@ -57,6 +57,10 @@ def test_conv2d(anylib, case, prec, monkeypatch):
         monkeypatch.setenv('LAMA_GEMM_WL', '0')
         monkeypatch.setenv('LAMA_GEMM_W4', '2')
         monkeypatch.setenv('LAMA_GEMM_W4_SLOTS', str(case['w4_slots']))
+    if 'wk_slots' in case:  # the spectral GEMM with all of K in one wave (gemm_wk_dev.inc), forced at these small sizes (profiling build switch)
+        monkeypatch.setenv('LAMA_GEMM_WL', '0')
+        monkeypatch.setenv('LAMA_GEMM_WK', '2')
+        monkeypatch.setenv('LAMA_GEMM_WK_SLOTS', str(case['wk_slots']))
     if 'cwt' in case:       # ConvTranspose2d as four parity-class launches: a switch of the profiling build (the product keeps the fused launch)
         monkeypatch.setenv('LAMA_CWT', str(case['cwt']))
     g = torch.Generator().manual_seed(1)
@@ -87,6 +91,7 @@ def test_conv2d(anylib, case, prec, monkeypatch):
 @pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
                                    (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64),
                                    (4, 384, 192, 1, 64, 64), (6, 384, 384, 1, 64, 33),   # persistent pointwise GEMM (conv_ws_dev.inc), K = 384
+                                   (8, 384, 384, 1, 64, 33), (4, 384, 384, 1, 128, 65),  # all of K in one wave (gemm_wk_dev.inc): 264 super-tiles = one round + the fifth waves; 520 = two + fifth waves
                                    (8, 192, 192, 1, 64, 64),                             # ... K = 192
                                    (2, 4, 64, 7, 512, 256),                              # stem kernel (conv_stem_dev.inc)
                                    (2, 64, 3, 7, 512, 416)])                             # head kernel (conv_head_dev.inc)
