@@ -343,10 +343,15 @@ def test_conv_linearity_full_size(lib, prec):
 
 @pytest.mark.parametrize('prec', [L.PREC_F16X3, L.PREC_BF16X3], ids=['f16x3', 'bf16x3'])
 @pytest.mark.parametrize('hw', [(64, 64), (9, 37)], ids=['c2_64x64', 'ragged_9x37'])
-def test_conv2d_fused_next_conv1(lib, prec, hw):
+def test_conv2d_fused_next_conv1(lib, lib_forced, prec, hw):
     """lama_conv2d_args.fuse1_*: SpectralTransform.conv1 of the next layer in the epilogue of the global-branch launch (3x3 over x_l +
     1x1 over t + bias + ReLU + residual -> 384 channels).  y is bit-identical to the plain launch; x1 equals conv1 run on y as a launch
-    of its own (same products, another summation order) and the fp64 reference."""
+    of its own (same products, another summation order) and the fp64 reference.  The ragged case is below the 160 tiles from which
+    production takes the 12-wave all-rows workgroup (the only one that carries conv1; smaller launches answer LAMA_ERR_UNSUPPORTED and
+    FFC.launch keeps conv1 a launch of its own): it runs on the profiling build with LAMA_CW_G12=2 (tests/emu.py)."""
+    if hw[0] != 64:
+        assert os.environ.get('LAMA_CW_G12') == '2'
+        lib = lib_forced
     g = torch.Generator().manual_seed(23)
     B, cl, cg, half, (H, W) = (8 if hw[0] == 64 else 2), 128, 384, 192, hw
     xl, t = torch.randn(B, cl, H, W, generator=g), torch.randn(B, half, H, W, generator=g)

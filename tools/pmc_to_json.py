@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Assemble profiles/<tag>_pmc.json (what bench.py's `traffic` fields read) from the summaries of tools/pmc_session.sh passes.
-usage: pmc_to_json.py <out.json> <how-text> <dir-with-p1/p2/p3.summary.txt> [<dir> ...]
+usage: pmc_to_json.py [--merge] <out.json> <how-text> <dir-with-p1/p2/p3.summary.txt> [<dir> ...]   (--merge: keep the entries of an existing <out.json> that the given directories do not replace)
 Every directory is one pmc_session over tools/kprobe.py; p1 = FETCH_SIZE, p2 = WRITE_SIZE, p3 = SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT."""
 import json
 import os
@@ -11,7 +11,7 @@ KEYS = [   # (bench key, kernel-name substrings summed into it, note)
     ('conv3x3_cin512_cout128_64x64', ['wino_gemm_kernel', 'wino_out_kernel'], 'local 3x3 conv as Winograd F(2x2,3x3): wino_gemm_kernel + wino_out_kernel (kprobe wino)', 86250000),
     ('conv3x3_cin128_cout384_64x64+1x1_cin192', ['conv_wr_kernel_f16x3<9, 2, 1, 4, 12, 1'], 'global 3x3 conv + fused 1x1 over t + residual (kprobe convB)', 144530000),
     ('conv1x1_cin384_cout192_64x64', ['gemm1x1_w4_kernel_f16x3<6, 2, false'], 'SpectralTransform.conv1 (kprobe conv1; same kernel name as the spectral GEMM: told apart by grid size)', 75500000),
-    ('conv1x1_cin384_cout384_64x33', ['gemm1x1_w4_kernel_f16x3<6, 2, false'], 'spectral 1x1 of the FourierUnit (kprobe fuconv)', 52500000),
+    ('conv1x1_cin384_cout384_64x33', ['gemm1x1_w4_kernel_f16x3<6, 2, false', 'gemm1x1_wk_kernel_f16x3'], 'spectral 1x1 of the FourierUnit (kprobe fuconv)', 52500000),
     ('rfft2_192x64x64', ['void rfft2_ip64_kernel'], 'rfft2 of 8 x 192 planes of 64 x 64', 51200000),
     ('irfft2_192x64x64', ['void irfft2_ip64_kernel'], 'irfft2 + residual', 76400000),
 ]
@@ -29,9 +29,14 @@ def parse(path):
 
 
 def main():
-    out_path, how = sys.argv[1], sys.argv[2]
+    merge = '--merge' in sys.argv
+    argv = [a for a in sys.argv if a != '--merge']
+    out_path, how = argv[1], argv[2]
     res = {'_how': how, 'f16x3': {}}
-    for d in sys.argv[3:]:
+    if merge and os.path.exists(out_path):
+        res = json.load(open(out_path))
+        res['_how'] = res.get('_how', '') + ' | ' + how
+    for d in argv[3:]:
         tag = os.path.basename(d.rstrip('/'))
         p = [parse(os.path.join(d, f'p{i}.summary.txt')) for i in (1, 2, 3)]
         for key, subs, note, alg in KEYS:
