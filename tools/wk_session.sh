@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box session of the spectral GEMM kernels: stand-alone harness (abtmp/wk_bench_<variant>, built by abtmp/mk_wk_bench.sh: wk with fifth waves /
+# same-box session of the spectral GEMM kernels: stand-alone harness (abtmp/wk_bench_<variant>, built by tools/ubench/mk_wk_bench.sh: wk with fifth waves /
 # wk without / w4, plain and with the memory accesses ablated, timeline of the wk kernel), then the parity tests that reach the kernel, then bench
 # A/B with the profiling library's switch.
 # usage (through gpurun): bash tools/wk_session.sh <tag> [harness|tests|ab ...]   (default: all three)
