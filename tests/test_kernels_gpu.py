@@ -91,7 +91,7 @@ def test_conv2d(anylib, case, prec, monkeypatch):
 @pytest.mark.parametrize('shape', [(2, 128, 128, 3, 64, 64), (2, 512, 128, 3, 64, 64), (1, 192, 384, 1, 64, 33), (1, 64, 3, 7, 96, 96),
                                    (1, 4, 64, 7, 128, 96), (1, 256, 128, 3, 40, 56), (1, 384, 192, 1, 64, 64),
                                    (4, 384, 192, 1, 64, 64), (6, 384, 384, 1, 64, 33),   # persistent pointwise GEMM (conv_ws_dev.inc), K = 384
-                                   (8, 384, 384, 1, 64, 33), (4, 384, 384, 1, 128, 65),  # all of K in one wave (gemm_wk_dev.inc): 264 super-tiles = one round + the fifth waves; 520 go to the w4 kernel
+                                   (8, 384, 384, 1, 64, 33), (2, 384, 384, 1, 128, 65), (4, 384, 384, 1, 128, 65),  # all of K in one wave (gemm_wk_dev.inc): 264 / 260 super-tiles = one round + the fifth waves; 520 go to the w4 kernel
                                    (8, 192, 192, 1, 64, 64),                             # ... K = 192
                                    (2, 4, 64, 7, 512, 256),                              # stem kernel (conv_stem_dev.inc)
                                    (2, 64, 3, 7, 512, 416)])                             # head kernel (conv_head_dev.inc)
