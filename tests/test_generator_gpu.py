@@ -199,6 +199,18 @@ def test_biglama_high_res_square(big, res):
     assert err < 1.5 * TOL, err
 
 
+def test_biglama_two_1024sq_spectral_gemm_one_wave(big):
+    """2 x 1024^2: the spectral 1x1 of every FourierUnit is 2 x 128 x 65 points = 260 super-tiles of 64 -- the second production shape of
+    gemm1x1_wk_kernel (all of K in one wave, gemm_wk_dev.inc: one round on 256 CUs + 4 left-over super-tiles = 96 units on the fifth
+    waves; 8 x 512^2 has 8 = 192), here inside the whole generator against the oracle."""
+    cfg, sd, gen, TOL = big
+    x, ref = _oracle_big(2, 1024, 1024, 7071)
+    y = gen(x.cuda()).cpu()
+    gen._plans.clear()
+    err = float((y - ref).abs().max())
+    assert err < 1.5 * TOL, err
+
+
 @pytest.mark.parametrize('shape', [(4, 1024), (2, 512), (1, 256)], ids=['c3_4x1024', '2x512', '1x256'])
 def test_biglama_fp16_activation_path(shape):
     """BASELINE configs[2] (big-lama 1024x1024 batch=4 fp16): PREC_F16 = fp16 activations in HBM between the stem and the head (the
