@@ -11,7 +11,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """The CPU suite (-m "not gpu": 339 emulator / oracle / host tests, about half an hour on one core, 6.5 minutes on eight) runs on up to eight
+    """The CPU suite (-m "not gpu": 340 emulator / oracle / host tests, about half an hour on one core, 6.5 minutes on eight) runs on up to eight
     pytest-xdist workers (one per core) when xdist is installed and nothing else was asked for; the GPU suite never does (one process owns the GPU, and the co-residency tests
     must not share it)."""
     if os.environ.get('PYTEST_XDIST_WORKER') or hasattr(config, 'workerinput'):     # a worker runs this hook too: it must never spawn workers
