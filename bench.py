@@ -8,8 +8,8 @@ hot path over one batch of synthetic input per rank: mask compose -> FFCResNetGe
 random-init weights of that architecture) -> blend -> u8 quantisation, on a batch of 8 images of
 512x512 that is already resident in HBM when the timed region starts (BASELINE configs[1];
 N ranks = configs[3] per rank).  N > 1: one process per GPU (torch.distributed over RCCL), images are
-sharded data-parallel (weak scaling, 8 per rank) and the only data-path collective is the all-gather
-of the u8 output images, inside the timed region.
+sharded data-parallel (weak scaling, 8 per rank) and the only data-path collective is the gather
+(to the writer rank 0) of the u8 output images, inside the timed region.
 
 The JSON line also carries
   roofline      -- the dominant kernel of the step (by total time): algorithmic FLOPs per launch /
@@ -54,6 +54,7 @@ if ROOT not in sys.path:
 
 from lama_amd import _lib as L  # noqa: E402
 from lama_amd import trainers  # noqa: E402
+from lama_amd.predict import gather_to_root  # noqa: E402
 
 BIG_LAMA = dict(
     kind='ffc_resnet', input_nc=4, output_nc=3, ngf=64, n_downsampling=3, n_blocks=18, add_out_act='sigmoid',
@@ -131,7 +132,13 @@ class KernelTimer:
         # algorithmic FLOPs of the launch (2*M*N*K; a transposed conv touches 9/4 taps per output pixel)
         kterm = x.C * k * k / (4.0 if tr else 1.0) + (x2.C if x2 is not None else 0)
         flops = 2.0 * batch * y.H * y.W * y.C * kterm
-        nbytes = 4.0 * batch * (x.C * x.H * x.W + y.C * y.H * y.W + (x2.C * x2.H * x2.W if x2 is not None else 0))
+        # algorithmic bytes of the launch: every operand once (x, the 1x1 segment's x2, the residual, the packed weights), y once
+        resid = kw.get('resid', a[6] if len(a) > 6 else None)
+        nbytes = 4.0 * batch * (x.C * x.H * x.W + y.C * y.H * y.W + (x2.C * x2.H * x2.W if x2 is not None else 0)
+                                + (y.C * y.H * y.W if resid is not None else 0))
+        for wp in (w_packed, kw.get('w2_packed')):
+            if torch.is_tensor(wp):
+                nbytes += wp.numel() * wp.element_size()
         f1 = kw.get('fuse1')
         if f1 is not None:      # SpectralTransform.conv1 of the next layer rides in this launch's epilogue: its flops and its output count here
             key += f'+next_conv1x1_cout{f1[2].C}'
@@ -170,11 +177,15 @@ def pmc_traffic(kernel_key, precision):
             d = json.load(open(f))
         except Exception:
             continue
-        e = d.get(precision, {}).get(kernel_key) or d.get(precision, {}).get(kernel_key.split('+next_')[0])
+        e = d.get(precision, {}).get(kernel_key)
         if e:
-            if '+next_' in kernel_key:
-                e = dict(e, note_fused='counters of the launch WITHOUT the fused conv1 of the next layer (+25 MB of x1 written)')
             return dict(e, source=os.path.relpath(f, ROOT))
+        e = d.get(precision, {}).get(kernel_key.split('+next_')[0])
+        if e:       # only the launch WITHOUT the fused conv1 of the next layer was profiled: not the launch that is timed -> no `traffic_bytes`
+            e = dict(e, source=os.path.relpath(f, ROOT))
+            return dict(traffic_bytes=None, unfused_launch=e,
+                        note='the committed counters describe this launch without the fused conv1 epilogue (+25 MB of x1 written); '
+                             'they are NOT the traffic of the launch avg_us / flops_per_launch / algorithmic_bytes describe')
     return None
 
 
@@ -405,7 +416,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    # LAMA_BENCH_FORCE_DIST=1: take the RCCL path (process group, all-gather, barrier, MAX all-reduce) with ONE rank too -- the only way to
+    # LAMA_BENCH_FORCE_DIST=1: take the RCCL path (process group, gather to rank 0, barrier, MAX all-reduce) with ONE rank too -- the only way to
     # exercise it on a single-GPU box (launched through torch.distributed.run --nproc-per-node 1)
     use_dist = world > 1 or (bool(int(os.environ.get('LAMA_BENCH_FORCE_DIST', '0'))) and 'RANK' in os.environ)
     if use_dist:
@@ -441,7 +452,8 @@ def main():
     # two (u8, gathered) buffer pairs, step k + 2 waits for gather k before it overwrites the pair.  Every gather is inside the timed
     # region: the closing barrier() synchronises the device, which drains the last two.
     u8_ring = [u8, torch.empty_like(u8)] if use_dist else [u8]
-    gathered = [torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) for _ in range(2)] if use_dist else None
+    # gather to the writer rank (rank 0), as predict.py does: the other ranks allocate and receive nothing
+    gathered = [torch.empty(world * BATCH, RES, RES, 3, dtype=torch.uint8, device=device) if rank == 0 else None for _ in range(2)] if use_dist else None
     comm_stream = torch.cuda.Stream(device=device) if use_dist else None
     quantized = [torch.cuda.Event() for _ in range(2)] if use_dist else None
     gather_work = [None, None]
@@ -459,7 +471,7 @@ def main():
             quantized[k].record(main)
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(quantized[k])
-                gather_work[k] = dist.all_gather_into_tensor(gathered[k], u8_ring[k], async_op=True)
+                gather_work[k] = gather_to_root(dist, gathered[k], u8_ring[k], rank, world)
             step_no[0] += 1
 
     def barrier():
@@ -470,6 +482,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # No host synchronisation inside a step: the fp16 split's range flag is not read back per forward (generator.defer_range_check) but
+    # ONCE, after the closing barrier and still inside the timed region -- a raised flag would void the run (checked below).
+    model.generator.defer_range_check = True
     for _ in range(args.warmup):
         step()
     barrier()
@@ -477,7 +492,11 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
+    range_ok = model.generator.check_range(device)
     dt = time.perf_counter() - t0
+    if not range_ok:
+        raise SystemExit('bench.py: an activation left the fp16 split\'s range during the timed steps: the run is void')
+    model.generator.defer_range_check = False
     if use_dist:
         tmax = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -637,9 +656,20 @@ def main():
             gbs = alg / kern[fu]['avg_us'] / 1e3
             parts = [pmc_traffic(k, args.precision) for k in ('rfft2_192x64x64', 'conv1x1_cin384_cout384_64x33', 'irfft2_192x64x64')]
             ffc_traffic = sum(p_['traffic_bytes'] for p_ in parts) if all(parts) else None
+            # what THIS design can reach at best: three launches that each move their own bytes once (x -> spectrum -> spectrum -> y + the
+            # residual re-read) at the measured-achievable 6.3 TB/s copy rate (MI355X_MICROARCH.md), launch boundaries not counted
+            three = (parts[0]['algorithmic_bytes'] + parts[1]['algorithmic_bytes'] + parts[2]['algorithmic_bytes']) if all(parts) else \
+                int(3.5 * alg)
+            ceil_us = three / 6.3e6
             roof_ffc = dict(unit_of_work=f'FourierUnit forward [{BATCH},192,{h},{h}] fp32 (3 launches)', bound='hbm', achieved=round(gbs, 1),
                             peak=HBM_PEAK_GBS, unit='GB/s', frac=round(gbs / HBM_PEAK_GBS, 4), traffic=ffc_traffic,
-                            avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg)
+                            traffic_source='replayed from the committed PMC passes (profiles/*pmc*.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                           '2 * FETCH + WRITE), NOT measured in this run: a live bench run cannot host the profiler',
+                            avg_us=round(kern[fu]['avg_us'], 2), algorithmic_bytes=alg,
+                            ceiling_three_launch=dict(bytes=three, us=round(ceil_us, 2), frac=round(alg / ceil_us / 1e3 / HBM_PEAK_GBS, 4),
+                                                      note='the cap of the three-launch design itself: both fp32 spectra round-trip through '
+                                                           'memory (181 MB against 51 MB algorithmic) at 6.3 TB/s; fp16-stored spectra would '
+                                                           'lift it but cost 6-7e-4 max-abs end to end (profiles/r04_fp16_spectrum_accuracy.txt)'))
             try:    # the coarser units beside it (serial-order kernel sums; MFMA utilisation is their primary figure)
                 def us(prefix):
                     ks = [k for k in kern if k.startswith(prefix)]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 106
+#define LAMA_HIP_VERSION 107
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -136,8 +136,17 @@ int lama_conv2d_fwd(void* stream, const lama_conv2d_args* args);
  *     split, MFMA A-fragment order; lama_winograd_packed_weight_bytes bytes.
  *   lama_winograd_conv3x3_fwd: args as lama_conv2d_fwd (x, w_packed, bias, act, resid, y, batch, precision, range_flag; kh = kw = 3,
  *     stride = 1, pad = 1, pad_mode = LAMA_PAD_REFLECT); workspace = lama_winograd_workspace_bytes device bytes (the half-inverted
- *     transform-domain sums between its two launches). */
+ *     transform-domain sums between its two launches).  x, y, resid: 16-byte aligned pointers, batch strides multiples of 4 elements
+ *     (else LAMA_ERR_UNSUPPORTED).
+ *   lama_winograd_supported: 1 when lama_winograd_conv3x3_fwd takes this (cout, cin, H, W, precision) -- every bound of the launch,
+ *     including the 32-bit byte offsets inside one image (cin * H * W * 4 < 2^31), which the workspace query alone does not see.
+ *   range_flag (LAMA_PREC_F16X3): NOT the same watch as lama_conv2d_fwd's.  It is kept on the row sums r of the input transform
+ *     (|V| <= 2 max|r|) and is raised at 2 max|r| >= 65504, i.e. up to 2x EARLY against a real overflow of a transformed operand, and it
+ *     is BLIND TO NaN inputs (fmaxf drops them).  Inside the generator the global-branch launch (lama_conv2d_fwd) reads the same state
+ *     buffer in the same layer and raises the flag for NaN / |x| > 65504; a stand-alone caller that needs NaN detection must run its own
+ *     check (or lama_conv2d_fwd) on x. */
 int64_t lama_winograd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t precision);
+int32_t lama_winograd_supported(int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t precision);
 int lama_winograd_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t precision, void* dst);
 size_t lama_winograd_workspace_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W);
 int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* args, void* workspace, size_t workspace_bytes);

@@ -17,7 +17,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 CONV_COOPERATIVE = 1
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 106      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 107      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -127,6 +127,7 @@ class LamaLib:
         L.lama_winograd_packed_weight_bytes.restype, L.lama_winograd_packed_weight_bytes.argtypes = C.c_int64, [i32, i32, i32]
         L.lama_winograd_pack_weight.restype, L.lama_winograd_pack_weight.argtypes = C.c_int, [vp, vp, vp, i32, i32, i32, vp]
         L.lama_winograd_workspace_bytes.restype, L.lama_winograd_workspace_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
+        L.lama_winograd_supported.restype, L.lama_winograd_supported.argtypes = i32, [i32, i32, i32, i32, i32]
         L.lama_winograd_conv3x3_fwd.restype, L.lama_winograd_conv3x3_fwd.argtypes = C.c_int, [vp, C.POINTER(Conv2dArgs), vp, C.c_size_t]
         del dp
         if L.lama_version() != ABI_VERSION:
@@ -200,7 +201,7 @@ class LamaLib:
     # -- Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect conv (lama_winograd_*) -----------------
     def winograd_supported(self, cout: int, cin: int, H: int, W: int, precision: int) -> bool:
         return (precision in (PREC_F16X3, PREC_BF16X3) and self._l.lama_winograd_packed_weight_bytes(cout, cin, precision) > 0
-                and self._l.lama_winograd_workspace_bytes(1, cout, H, W) > 0)
+                and self._l.lama_winograd_supported(cout, cin, H, W, precision) == 1)
 
     def winograd_workspace_bytes(self, batch: int, cout: int, H: int, W: int) -> int:
         return int(self._l.lama_winograd_workspace_bytes(batch, cout, H, W))

@@ -24,7 +24,7 @@ SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'conv_f16.hip',
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'gemm_wk_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'), os.path.join(CSRC, 'wino_dev.inc'), os.path.join(CSRC, 'convt_dev.inc'),
            os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
 # Every translation unit is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
-# Measured on MI355X / ROCm 7.2 (tools/race_probe5-9.py): a v_pk_*_f32 with an op_sel half-swizzle returns wrong
+# Measured on MI355X / ROCm 7.2 (tools/race_probe8.py, race_probe9.py; probes 1-7 in the git history): a v_pk_*_f32 with an op_sel half-swizzle returns wrong
 # results while a wave of ANOTHER kernel executes MFMA instructions on the same SIMD (an inline-asm probe of that one instruction
 # fails 60 / 60 next to a bare MFMA loop, the plain forms pass).  hipcc's SLP vectoriser emits thousands of them for the float2
 # butterflies of the FFT kernels, which therefore produced wrong planes in up to 99 % of the runs next to a convolution on a second

@@ -143,7 +143,10 @@ class _Exec:
             _check_input(x)
 
     @contextlib.contextmanager
-    def range_scope(self, t: torch.Tensor, precision: int):
+    def range_scope(self, t: torch.Tensor, precision: int, deferred: bool = False):
+        """``deferred``: the outermost scope does NOT read the flag back (no host synchronisation: forwards can queue behind one another);
+        the flag stays raised on the device -- the kernels only ever OR into it -- until ``check_range`` reads it at the caller's next
+        synchronisation point (FFCResNetGenerator.defer_range_check)."""
         outer = self._depth == 0
         if outer and precision in (L.PREC_F16X3, L.PREC_F16):
             key = str(t.device)
@@ -161,10 +164,21 @@ class _Exec:
         self._depth -= 1
         if outer:
             flag, self._cur_flag = self._cur_flag, None
-            if flag is not None and int(flag.item()) != 0:
+            if flag is not None and not deferred and int(flag.item()) != 0:
                 flag.zero_()
-                raise LamaRangeError('an activation left the range of the fp16 split (|x| > 65504 or NaN) in this forward; '
-                                     're-run with precision bf16x3 (fp32 exponent range) or f32')
+                raise LamaRangeError(_RANGE_MSG)
+
+    def range_flag_raised(self, device=None) -> bool:
+        """Read back AND clear (one 4-byte D2H per device = a host synchronisation with that device's current stream) the flag(s) that deferred
+        scopes left on the device: True when a forward since the last read split an activation beyond 65504 (or a NaN)."""
+        bad = False
+        for key, flag in self._flags.items():
+            if device is not None and key != str(torch.device(device)):
+                continue
+            if int(flag.item()) != 0:
+                flag.zero_()
+                bad = True
+        return bad
 
     def conv2d(self, *a, **kw):
         flag = self._cur_flag if kw.get('precision') in (L.PREC_F16X3, L.PREC_F16) else None
@@ -179,6 +193,8 @@ class _Exec:
         self.lib.winograd_conv3x3(*a, precision=precision, range_flag=flag, **kw)
 
 
+_RANGE_MSG = ('an activation left the range of the fp16 split (|x| > 65504 or NaN) in this forward; '
+              're-run with precision bf16x3 (fp32 exponent range) or f32')
 _DEFAULT_EXEC = _Exec()
 
 
@@ -464,11 +480,16 @@ class FFC(_HipModule):
             """out_xl = act(bn(convl2l(x_l) + convg2l(x_g))) [+ residual]: one 3x3 over the whole state buffer (ffc.py:220)."""
             rl = None if resid is None else L.view(resid, 0, ocl)
             if wino:
-                ex.winograd_conv3x3(L.view(src), pk['w_lout_wino'], L.view(dst, 0, ocl), B, scratch['wino'], pk['b_l'], act, rl, precision=prec,
-                                    stream=stream)
-            else:
-                ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act, rl, precision=prec,
-                          stream=stream, cooperative=cooperative)
+                try:
+                    ex.winograd_conv3x3(L.view(src), pk['w_lout_wino'], L.view(dst, 0, ocl), B, scratch['wino'], pk['b_l'], act, rl, precision=prec,
+                                        stream=stream)
+                    return
+                except LamaError as e:      # a view the Winograd entry does not take (alignment, 32-bit offsets of very tall planes): the direct kernel
+                    if e.code != L.ERR_UNSUPPORTED:
+                        raise
+                    scratch['wino'] = None
+            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_l'], act, rl, precision=prec,
+                      stream=stream, cooperative=cooperative)
 
         if isinstance(side, SidePipe) and src.is_cuda:
             main = torch.cuda.current_stream(src.device)
@@ -882,6 +903,11 @@ class FFCResNetGenerator(_HipModule):
         # (or a NaN) was met the forward is repeated with the 3-term bf16 split (fp32 exponent range) and the generator stays
         # on it.  auto_fallback = False raises LamaRangeError instead.
         self.auto_fallback = True
+        # True: ``forward`` does NOT read the flag back (no host synchronisation per forward: step k + 1 queues behind step k, and a serving
+        # loop's launch thread never waits for the GPU); the flag stays raised on the device and the CALLER asks at its own synchronisation
+        # point -- ``check_range()`` -- before it trusts the results produced since the last check.  predict.py (per bucket) and bench.py
+        # (closing barrier of the timed region) run this way.  Default False: a plain ``generator(x)`` is self-checking like the reference.
+        self.defer_range_check = False
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
@@ -963,7 +989,14 @@ class FFCResNetGenerator(_HipModule):
         # global launch's epilogue (round 3, same box: 716 / 714 / 720-724 images/s for two streams / one / one + fused conv1,
         # profiles/r03_ab_launch_order.txt).  Elsewhere (planes the Winograd kernel does not take) the round-2 order stays: the spectral
         # branch on a second stream beside the cooperative direct conv.
-        wino = bool(scratch and scratch.get('wino') is not None and self._exec.winograd)
+        # (the predicate FFC.launch uses: the workspace exists AND every residual layer holds Winograd-packed weights -- a transformed
+        # weight beyond the fp16 range keeps the direct kernel, FFC.pack -- otherwise the direct local conv would run on one stream in
+        # its non-cooperative geometry with nothing beside it)
+        res_layers = [l for st_ in steps if st_[0] == 'res' for l in (st_[1].conv1, st_[1].conv2)]
+        wino = bool(scratch and scratch.get('wino') is not None and self._exec.winograd and res_layers
+                    and all('w_lout_wino' in l._pack() for l in res_layers))
+        if scratch and scratch.get('wino') is not None and not wino:
+            scratch['wino'] = None                   # 33 MB at 8 x 64 x 64 that no launch would read
         serial = wino and self.serial_with_winograd
         side = torch.cuda.Stream(device=device) if (self.overlap_streams and not serial and torch.device(device).type == 'cuda') else None
         return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None, side=side,
@@ -1008,7 +1041,7 @@ class FFCResNetGenerator(_HipModule):
         self._exec.check(input)
         x = input.contiguous()
         try:
-            with self._exec.range_scope(x, self.precision):
+            with self._exec.range_scope(x, self.precision, deferred=self.defer_range_check):
                 return self._forward(x)
         except LamaRangeError as e:
             if not self.auto_fallback or self.precision not in (L.PREC_F16X3, L.PREC_F16):
@@ -1016,6 +1049,23 @@ class FFCResNetGenerator(_HipModule):
             warnings.warn(f'lama_amd: {e}; switching this generator to the 3-term bf16 split (PREC_BF16X3)')
             self.set_precision(L.PREC_BF16X3)
             return self.forward(input)
+
+    def check_range(self, device=None, reduce=None) -> bool:
+        """The other half of ``defer_range_check``: one 4-byte read-back (a host synchronisation) of the range flag the forwards since the last
+        check have been OR-ing into.  Returns True when every one of them stayed inside the fp16 split's range.  Otherwise their results are NOT
+        valid: with ``auto_fallback`` the generator switches to the 3-term bf16 split and False is returned -- the caller re-runs those inputs --
+        without it LamaRangeError is raised.  ``reduce`` (multi-rank callers): bool -> bool, the OR over all ranks, called UNCONDITIONALLY (a
+        collective), so that every rank switches precision and re-runs alike."""
+        bad = self._exec.range_flag_raised(device)
+        if reduce is not None:
+            bad = bool(reduce(bad))
+        if not bad:
+            return True
+        if not self.auto_fallback or self.precision not in (L.PREC_F16X3, L.PREC_F16):
+            raise LamaRangeError(_RANGE_MSG)
+        warnings.warn(f'lama_amd: {_RANGE_MSG}; switching this generator to the 3-term bf16 split (PREC_BF16X3): re-run the inputs since the last check')
+        self.set_precision(L.PREC_BF16X3)
+        return False
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
         key = (tuple(x.shape), str(x.device))

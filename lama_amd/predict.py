@@ -159,6 +159,19 @@ def plan_rounds(shapes: Sequence[Tuple[int, int]], batch_size: int, world: int) 
     return rounds
 
 
+def gather_to_root(dist, gathered: Optional[torch.Tensor], part: torch.Tensor, rank: int, world: int, root: int = 0):
+    """The data path's only collective: the u8 result images of every rank to the WRITER rank.  ``dist.gather`` (RCCL: one
+    send per non-root rank, ``world - 1`` receives on the root, point-to-point over xGMI) -- the other ranks allocate and receive nothing,
+    unlike an all-gather, which moves ``world`` times the bytes to deliver copies nobody reads.  ``gathered`` = [world * n, ...] on the root,
+    None elsewhere.  Returns the asynchronous work handle."""
+    parts = list(gathered.chunk(world, dim=0)) if rank == root else None          # contiguous slices of the root's buffer: no staging copy
+    return dist.gather(part, gather_list=parts, dst=root, async_op=True)
+
+
+class _RangeRestart(Exception):
+    """A forward of this run left the fp16 split's range: the generator is on the bf16 split now, the run starts over."""
+
+
 def _write_png(path: str, rgb: np.ndarray):
     from PIL import Image
     os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -177,6 +190,23 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
     Host pipeline: the PNGs of round r + 1 are decoded / padded on the thread pool while round r computes, results are
     written on the same pool; a partial last batch of a bucket is zero-padded to ``batch_size`` so that it replays the bucket's
     captured plan instead of building (and capturing) a second one, and a bucket's plan is dropped when the bucket is done."""
+    gen = model.generator
+    keep = gen.defer_range_check
+    # no host synchronisation per forward: the fp16 split's range flag is read once per bucket, where every rank synchronises anyway
+    gen.defer_range_check = True
+    try:
+        for _attempt in range(2):
+            try:
+                return _predict_once(model, items, indir, outdir, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext, device=device,
+                                     rank=rank, world=world, dist=dist, io_threads=io_threads)
+            except _RangeRestart:
+                continue                     # the generator switched to the 3-term bf16 split (every rank alike): all images again
+        raise L.LamaError('range restart did not converge')
+    finally:
+        gen.defer_range_check = keep
+
+
+def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, device, rank, world, dist, io_threads) -> int:
     from PIL import Image
     shapes, sizes = [], []
     for _, im_path in items:                 # padded shape from the IMAGE's PNG header only: every rank builds the same plan
@@ -202,7 +232,7 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
             staging.clear()                     # buckets are visited one after the other: keep one shape's buffers
             staging[(Hp, Wp)] = (torch.zeros(batch_size, 3, Hp, Wp, dtype=torch.float32, pin_memory=on_gpu),
                                  torch.zeros(batch_size, 1, Hp, Wp, dtype=torch.float32, pin_memory=on_gpu),
-                                 torch.zeros(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, pin_memory=on_gpu))
+                                 torch.zeros(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, pin_memory=on_gpu) if rank == 0 else None)
         return staging[(Hp, Wp)]
 
     # the pinned staging buffers are refilled in place every round: the H2D copies of round r must have run before the host writes
@@ -276,13 +306,13 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(u8.device))
         if world > 1:
-            gathered = torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
+            gathered = torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device) if rank == 0 else None
             if on_gpu:
                 with torch.cuda.stream(side):
                     side.wait_event(done)
-                    work = dist.all_gather_into_tensor(gathered, u8, async_op=True)
+                    work = gather_to_root(dist, gathered, u8, rank, world)
             else:
-                work = dist.all_gather_into_tensor(gathered, u8, async_op=True)
+                work = gather_to_root(dist, gathered, u8, rank, world)
         else:
             gathered = u8
         last_of_bucket = ri + 1 == len(rounds) or rounds[ri + 1]['shape'] != rd['shape']
@@ -295,6 +325,18 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
             if on_gpu:
                 torch.cuda.current_stream(u8.device).synchronize()                  # every rank: the graph / buffers below are in flight
                 h2d_pending = False
+            # the bucket's ONE read-back of the fp16 split's range flag (the forwards above did not synchronise); all ranks decide alike
+            def red(bad, _dev=u8.device):
+                t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=_dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return int(t.item()) != 0
+            if world <= 1:
+                red = None
+            if not model.generator.check_range(u8.device, reduce=red):
+                for f in futures:
+                    f.result()
+                pool.shutdown()
+                raise _RangeRestart()
             model.generator.drop_plan((batch_size, 4, Hp, Wp), u8.device)           # bucket done: free its buffers / graph
     for f in futures:
         f.result()

@@ -6,7 +6,6 @@ import sys
 # small test shapes must reach the full-M 1x1 workgroups too (conv_wreg_host.inc reads this once)
 os.environ.setdefault('LAMA_CW_1X1', '2')
 os.environ.setdefault('LAMA_GEMM_WS', '2')
-os.environ.setdefault('LAMA_GEMM_WL', '2')
 os.environ.setdefault('LAMA_STEM_WS', '2')
 os.environ.setdefault('LAMA_HEAD_WS', '2')
 # ... and the 12-wave all-rows workgroup of the global branch (production takes it from 160 tiles on: conv_wreg_host.inc)

@@ -1,6 +1,6 @@
 """bench.py's driver contract on the GPU box, through the path a multi-GPU run takes: `python bench.py --gpus N` without a
 torch.distributed environment re-executes itself under torch.distributed.run, the ranks form an RCCL ('nccl') process group, every step
-ends in the all-gather of the u8 output images, the timed region is bracketed by barrier + synchronize and the time is the MAX over
+ends in the gather (to rank 0) of the u8 output images, the timed region is bracketed by barrier + synchronize and the time is the MAX over
 ranks.  A single-GPU box can host one rank only (LAMA_BENCH_FORCE_DIST=1 takes that path with world_size 1); the world_size-2 logic is
 covered on CPU by tests/test_dist_gloo.py."""
 import json

@@ -1,5 +1,5 @@
 """world_size-2 CPU tests (gloo) of the data-parallel predict path (lama_amd.predict): shape bucketing, round-robin
-sharding of batches over ranks, the single all-gather of u8 output images, and the on-disk contract of bin/predict.py.
+sharding of batches over ranks, the single gather (to the writer rank) of u8 output images, and the on-disk contract of bin/predict.py.
 The kernels run through the host SIMT emulator (tests/hipemu); the expected PNGs come from the oracle's restatement of
 the reference's batch-1 predict loop."""
 import os

@@ -56,16 +56,13 @@ CONV_CASES = [
     dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=3),
     dict(cin=64, cout=256, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True, geo=2),
     dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=2),
-    # ... ConvTranspose2d as four output-parity classes on the weights-in-registers kernel (cwt_try_launch: cin % 64 == 0, cout % 128 == 0),
-    # forced at any launch size with LAMA_CWT=2; ragged tiles, narrow image (16-pixel tile rows), two M tiles, two 64-channel chunks
-    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=6, W=35, act=1, bias=True, resid=False, scale=True, transposed=True, cwt=2),
-    dict(cin=128, cout=256, k=3, stride=2, pad=1, H=9, W=10, act=0, bias=False, resid=False, scale=False, transposed=True, cwt=2),
-    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=6, W=35, act=1, bias=True, resid=False, scale=True, transposed=True, cwt=0),   # the fused launch on the same shape
     # ... ConvTranspose2d as ONE launch of class-specialised waves (convt_dev.inc: cin % 32 == 0, cout % 64 == 0, W % 32 == 0, H % 4 == 0): one
     # tile / one chunk; 2 x 2 tiles, two chunks, two 64-row groups; and the fused LDS-staged launch on the same shape (LAMA_CT=0)
     dict(cin=32, cout=64, k=3, stride=2, pad=1, H=4, W=32, act=1, bias=True, resid=False, scale=True, transposed=True),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True, ct=0),
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=1, bias=True, resid=False, scale=True, transposed=True, ct=3),      # the round-3 class-specialised kernel (profiling switch)
+    dict(cin=128, cout=64, k=3, stride=2, pad=1, H=12, W=32, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=2),  # up3's channel counts: 8 sub-chunks, 6 tiles on 2 workgroups
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=3),   # 16 tiles on 3 persistent workgroups
     # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
     dict(cin=32, cout=128, k=3, stride=2, pad=1, H=16, W=70, act=1, bias=True, resid=False, scale=True),
@@ -78,17 +75,6 @@ CONV_CASES = [
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True),
     dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False),
     dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True),      # rows past M in the last fragment
-    # ... the same three on the round-2 weights-in-registers kernel (LAMA_GEMM_WL=0), and the weights-in-LDS kernel with ONE workgroup per row
-    # group (LAMA_GEMM_WL_SLOTS=1: 8 waves) so that a few tiles make whole rounds + (tile, fragment) thirds / an extra whole tile
-    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True, wl=0),
-    dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=False, scale=False, wl=0),
-    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True, wl=0),
-    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=5, W=21, act=1, bias=True, resid=True, scale=True, wl_slots=1),      # 8 tiles on 8 waves: one whole round
-    dict(cin=384, cout=180, k=1, stride=1, pad=0, H=8, W=33, act=2, bias=True, resid=False, scale=True, wl_slots=1),   # 18 tiles: two rounds + 6 thirds
-    dict(cin=192, cout=384, k=1, stride=1, pad=0, H=3, W=50, act=0, bias=False, resid=True, scale=False, wl_slots=1),   # 10 tiles: one round + 6 thirds, residual
-    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=31, act=1, bias=True, resid=False, scale=True, wl_slots=1),     # 14 tiles: one round + 6 whole left-overs
-    dict(cin=384, cout=96, k=1, stride=1, pad=0, H=4, W=32, act=1, bias=True, resid=True, scale=True, wl=2),            # whole tiles only: 16-byte stores through the wave's LDS transpose
-    dict(cin=192, cout=192, k=1, stride=1, pad=0, H=8, W=16, act=2, bias=True, resid=False, scale=False, wl_slots=1),   # ... two row groups, 8 tiles on 8 waves
     # ... and over 64-pixel super-tiles of two interleaved MFMA tiles (gemm1x1_w4_kernel; LAMA_GEMM_W4=2 forces it at any launch size, LAMA_GEMM_W4_SLOTS
     # caps the workgroups per row group): super-tiles across the image boundary, groups past the batch, several rounds, left-over super-tiles, K = 192
     dict(cin=384, cout=96, k=1, stride=1, pad=0, H=7, W=38, act=1, bias=True, resid=True, scale=True, w4_slots=0),        # 532 pixels = 8.3 super-tiles, one round
@@ -120,29 +106,21 @@ CONV_TOL = {L.PREC_F32: dict(atol=2e-4, rtol=1e-4), L.PREC_BF16X3: dict(atol=6e-
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'wks%d' % c['wk_slots'] if 'wk_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'geo%d' % c['geo'] if c.get('geo') else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'wks%d' % c['wk_slots'] if 'wk_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d_emulated(case, prec, monkeypatch):
     lib = emu_lib()
     if 'ct' in case:
         monkeypatch.setenv('LAMA_CT', str(case['ct']))
     if 'ct_grid' in case:
         monkeypatch.setenv('LAMA_CT_GRID', str(case['ct_grid']))
-    if 'wl' in case:
-        monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
     if 'w4_slots' in case:
-        monkeypatch.setenv('LAMA_GEMM_WL', '0')
         monkeypatch.setenv('LAMA_GEMM_W4', '2')
         monkeypatch.setenv('LAMA_GEMM_W4_SLOTS', str(case['w4_slots']))
     if 'wk_slots' in case:
-        monkeypatch.setenv('LAMA_GEMM_WL', '0')
         monkeypatch.setenv('LAMA_GEMM_WK', '2')
         monkeypatch.setenv('LAMA_GEMM_WK_SLOTS', str(case['wk_slots']))
-    if 'wl_slots' in case:
-        monkeypatch.setenv('LAMA_GEMM_WL_SLOTS', str(case['wl_slots']))
     if case.get('geo'):
         monkeypatch.setenv('LAMA_CW_41', str(case['geo']))
-    if 'cwt' in case:
-        monkeypatch.setenv('LAMA_CWT', str(case['cwt']))
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)

@@ -42,27 +42,19 @@ DEV = 'cuda'
 
 
 @pytest.mark.parametrize('prec', PRECISIONS, ids=PREC_IDS)
-@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'cwt%d' % c['cwt'] if 'cwt' in c else ''}{'wl%d' % c['wl'] if 'wl' in c else ''}{'wls%d' % c['wl_slots'] if 'wl_slots' in c else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'wks%d' % c['wk_slots'] if 'wk_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: f"k{c['k']}s{c['stride']}c{c['cin']}o{c['cout']}{'T' if c.get('transposed') else ''}{'w4s%d' % c['w4_slots'] if 'w4_slots' in c else ''}{'wks%d' % c['wk_slots'] if 'wk_slots' in c else ''}{'ct%d' % c['ct'] if 'ct' in c else ''}{'ctg%d' % c['ct_grid'] if 'ct_grid' in c else ''}")
 def test_conv2d(anylib, case, prec, monkeypatch):
     lib = anylib
     if 'ct' in case:
         monkeypatch.setenv('LAMA_CT', str(case['ct']))
     if 'ct_grid' in case:
         monkeypatch.setenv('LAMA_CT_GRID', str(case['ct_grid']))
-    if 'wl' in case:        # pointwise GEMM: the round-2 weights-in-registers kernel (profiling build switch)
-        monkeypatch.setenv('LAMA_GEMM_WL', str(case['wl']))
-    if 'wl_slots' in case:
-        monkeypatch.setenv('LAMA_GEMM_WL_SLOTS', str(case['wl_slots']))
     if 'w4_slots' in case:  # pointwise GEMM over super-tiles of interleaved MFMA tiles, forced at these small sizes (profiling build switch)
-        monkeypatch.setenv('LAMA_GEMM_WL', '0')
         monkeypatch.setenv('LAMA_GEMM_W4', '2')
         monkeypatch.setenv('LAMA_GEMM_W4_SLOTS', str(case['w4_slots']))
     if 'wk_slots' in case:  # the spectral GEMM with all of K in one wave (gemm_wk_dev.inc), forced at these small sizes (profiling build switch)
-        monkeypatch.setenv('LAMA_GEMM_WL', '0')
         monkeypatch.setenv('LAMA_GEMM_WK', '2')
         monkeypatch.setenv('LAMA_GEMM_WK_SLOTS', str(case['wk_slots']))
-    if 'cwt' in case:       # ConvTranspose2d as four parity-class launches: a switch of the profiling build (the product keeps the fused launch)
-        monkeypatch.setenv('LAMA_CWT', str(case['cwt']))
     g = torch.Generator().manual_seed(1)
     B, cin, cout, k = 2, case['cin'], case['cout'], case['k']
     tr = case.get('transposed', False)

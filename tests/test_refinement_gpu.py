@@ -165,3 +165,50 @@ def test_refine_predict_biglama_golden(biglama_module, golden_dir, res, precs):
     moved = float(np.abs(out[:, :, ::st, ::st].numpy() - g['plain_sample']).mean())
     assert moved > 0.3 * float(g['refine_minus_plain_meanabs'][0]), (moved, g['refine_minus_plain_meanabs'])
     print('\n'.join(report))
+
+
+@pytest.mark.parametrize('precs', [(L.PREC_F32, L.PREC_F32), (L.PREC_F16X3, None)], ids=['exact_f32', 'default_f16x3_fwd_bf16x3_bwd'])
+def test_first_iteration_gradient_18_blocks(biglama_module, golden_dir, precs):
+    """The FIRST refinement iteration through ALL 18 FFCResnetBlocks at 512 x 512 (refinement.py:131-165): the prediction ``pred0`` and the
+    gradient that ``loss.backward()`` leaves on (z1, z2), against the committed sample of the CPU oracle (torch autograd;
+    tests/golden/make_golden_refine_grad.py).  Holds the explicit reverse pass (lama_amd/backward.py) at full depth -- 36 FourierUnit adjoints,
+    36 x 3 dgrad 3x3 convs, three ConvTranspose2d adjoints and the head -- where ``test_rear_gradients_full_channel_count`` has two blocks.
+
+    Bars.  pred0: relative L2 <= 1e-4 (exact fp32; measured ~2e-6) / 3e-4 (f16x3 forward).  Gradient: the loss is an L1, so its derivative with
+    respect to the prediction is sign(pred - image) / N and every pixel whose prediction lies within rounding distance of its target flips; the
+    golden file carries the oracle's OWN distance to itself under a relative 2e-6 perturbation of z (1.16e-2 relative L2) and the HIP gradient
+    must stay within 2x that of the golden -- and correlate with it to better than 0.999 (a wrong adjoint anywhere in the 18 blocks does not)."""
+    path = os.path.join(golden_dir, 'refine_grad_biglama_512.npz')
+    g = np.load(path)
+    model, checksum = biglama_module
+    assert abs(checksum - float(g['sd_checksum'][0])) < 1e-3 * abs(checksum), 'seeded weights drifted from the golden run'
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_golden_refine', os.path.join(golden_dir, 'make_golden_refine.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    image, mask = mk.make_case(res=512, seed=int(g['seed_img'][0]))
+    batch = dict(image=image.cuda(), mask=mask.cuda(), unpad_to_size=[torch.tensor([512]), torch.tensor([512])])
+    trace = []
+    model.generator.set_precision(precs[0])
+    try:
+        RF.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=2, lr=0.002, min_side=256, max_scales=2, px_budget=10 ** 8,
+                          trace=trace, bwd_precision=precs[1])
+    finally:
+        model.generator.set_precision(L.PREC_F16X3)
+    assert len(trace) == 2 and len(trace[1]['loss']) == 2
+    gs, ps = int(g['strides'][0]), int(g['strides'][1])
+    pred0 = trace[1]['pred0'].cpu()[:, :, ::ps, ::ps].numpy()
+    gz = trace[1]['g_z'].cpu()
+    assert gz.shape == (1, 512, 64, 64)
+    rel_p = float(np.linalg.norm(pred0 - g['pred0_sample']) / np.linalg.norm(g['pred0_sample']))
+    got, ref = gz[:, :, ::gs, ::gs].numpy().astype(np.float64), g['g_sample'].astype(np.float64)
+    rel_g = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    corr = float((got * ref).sum() / (np.linalg.norm(got) * np.linalg.norm(ref)))
+    norm_ratio = float(gz.double().norm()) / float(g['g_norm'][0])
+    loss_rel = np.abs(np.asarray(trace[1]['loss']) - g['loss']) / g['loss']
+    print(f'pred0 rel L2 {rel_p:.2e}; gradient rel L2 {rel_g:.2e} (oracle vs itself {float(g["self_rel"][1]):.2e}), corr {corr:.5f}, '
+          f'|g| ratio {norm_ratio:.4f}; loss rel {loss_rel.max():.1e}', flush=True)
+    assert rel_p < (1e-4 if precs[0] == L.PREC_F32 else 3e-4), rel_p
+    assert loss_rel.max() < 1e-4, loss_rel
+    assert rel_g < 2.0 * float(g['self_rel'][1]), (rel_g, g['self_rel'])
+    assert corr > 0.999 and abs(norm_ratio - 1.0) < 5e-3, (corr, norm_ratio)
