@@ -56,12 +56,12 @@ CONV_CASES = [
     dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=3),
     dict(cin=64, cout=256, k=3, stride=1, pad=1, H=7, W=37, act=1, bias=True, resid=True, scale=True, geo=2),
     dict(cin=96, cout=128, k=3, stride=1, pad=1, H=9, W=12, act=0, bias=False, resid=False, scale=False, geo=2),
-    # ... ConvTranspose2d as ONE launch of class-specialised waves (convt_dev.inc: cin % 32 == 0, cout % 64 == 0, W % 32 == 0, H % 4 == 0): one
+    # ... ConvTranspose2d as ONE launch with all four parity classes in a wave (convt2_kernel, convt_dev.inc: cin % 32 == 0, cout % 64 == 0, W % 32 == 0, H % 4 == 0): one
     # tile / one chunk; 2 x 2 tiles, two chunks, two 64-row groups; and the fused LDS-staged launch on the same shape (LAMA_CT=0)
     dict(cin=32, cout=64, k=3, stride=2, pad=1, H=4, W=32, act=1, bias=True, resid=False, scale=True, transposed=True),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True, ct=0),
-    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=1, bias=True, resid=False, scale=True, transposed=True, ct=3),      # the round-3 class-specialised kernel (profiling switch)
+    dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=2, bias=True, resid=False, scale=True, transposed=True),            # sigmoid: not convt2_kernel's epilogue -> the fused LDS-staged launch
     dict(cin=128, cout=64, k=3, stride=2, pad=1, H=12, W=32, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=2),  # up3's channel counts: 8 sub-chunks, 6 tiles on 2 workgroups
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=3),   # 16 tiles on 3 persistent workgroups
     # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
