@@ -365,9 +365,9 @@ def configs2_leg(model, device, lib, args):
         out[name] = dict(value=round(4 / dt, 2), unit='images/s', ms_per_step=round(dt * 1e3, 3), steps=n)
         model.generator._plans.clear()
     out['workload'] = 'big-lama 1024x1024 batch=4, mask-compose + generator + blend + u8, hipGraph replay'
-    out['dtype_f16'] = ('fp16 activations in HBM (fp32 residual stream), weights as hi + lo fp16 parts (2 MFMA products per MAC), fp32 accumulate; '
-                        'measured 1.7e-2 max / 4.0e-4 mean-abs vs the fp32 oracle at 4x1024^2, the oracle with fp16-rounded conv inputs alone: 1.6e-2 max '
-                        '(profiles/r03_fp16_two_products.txt; one product per MAC: 2.1e-2 / 6.0e-4 and 27 % faster)')
+    out['dtype_f16'] = ('fp16 activations in HBM from the stem output through the resnet blocks (fp32 residual stream; round 4: the three upsampled tensors and '
+                        'the head stay fp32 / 3-term split), weights as hi + lo fp16 parts (2 MFMA products per MAC), fp32 accumulate; the oracle with the '
+                        'same storage roundings: 3.4e-3 max / 3.0e-4 mean-abs vs the fp32 oracle at 1x1024^2 (round-3 layout: 1.1e-2; tools/fp16_by_tensor.py)')
     torch.cuda.empty_cache()
     return out
 

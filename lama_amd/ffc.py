@@ -237,8 +237,12 @@ class _HipModule(nn.Module):
         for m in self.modules():
             if isinstance(m, _HipModule):
                 m.precision = precision
+        self._precision_hook(precision)
         self._invalidate()          # packed weights and captured graphs belong to the old precision
         return self
+
+    def _precision_hook(self, precision: int):
+        """Per-layer exceptions to a uniform precision (FFCResNetGenerator: the fp32 tail of LAMA_PREC_F16)."""
 
     def train(self, mode: bool = True):
         if mode:
@@ -908,6 +912,12 @@ class FFCResNetGenerator(_HipModule):
         # point -- ``check_range()`` -- before it trusts the results produced since the last check.  predict.py (per bucket) and bench.py
         # (closing barrier of the timed region) run this way.  Default False: a plain ``generator(x)`` is self-checking like the reference.
         self.defer_range_check = False
+        # LAMA_PREC_F16 (fp16 activations in HBM, BASELINE configs[2]): the layers BEHIND the resnet blocks -- the three ConvTranspose2d + BN + ReLU and
+        # the 7x7 head -- keep fp32 tensors and the 3-term split.  Measured on the oracle with a rounding to fp16 wherever the path has one
+        # (tools/fp16_by_tensor.py, 1 x 1024^2): every ONE of the three upsampled tensors in fp16 costs 5-9e-3 max-abs on its own (the features
+        # are largest behind the 18 blocks).  On the GPU at 4 x 1024^2: 1.68e-2 -> 1.19e-2 max-abs for 218 -> 210 images/s.
+        # False = the round-3 layout (everything between stem and head fp16).
+        self.f16_fp32_tail = True
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
@@ -915,6 +925,15 @@ class FFCResNetGenerator(_HipModule):
         super().train(False)
 
     # ------------------------------------------------------------------------------------------------
+    def _precision_hook(self, precision: int):
+        if precision != L.PREC_F16 or not getattr(self, 'f16_fp32_tail', False):
+            return
+        tail = False
+        for lay in self.model:
+            tail = tail or isinstance(lay, ConcatTupleLayer)
+            if tail and isinstance(lay, _HipModule):
+                lay.precision = L.PREC_F16X3             # fp32 tensors, fp32-accurate arithmetic
+
     def _invalidate(self):
         super()._invalidate()
         self._plans = collections.OrderedDict()
@@ -964,7 +983,7 @@ class FFCResNetGenerator(_HipModule):
                 act = layers[i + 2] if bn is not None and i + 2 < n and isinstance(layers[i + 2], Activation) else None
                 B, _, H, W = cur_shape
                 shp = (B, lay.out_channels, 2 * H, 2 * W)
-                dst = new(f'a{k}', shp); k += 1
+                dst = new(f'a{k}', shp, _act_dtype(lay.precision)); k += 1
                 if bn is not None and act is not None:
                     steps.append(('up', lay, cur, dst, bn, _ACT[act.kind])); i += 2
                 else:

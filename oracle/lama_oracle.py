@@ -245,6 +245,75 @@ def generator_forward_fp16_emulated(x: Tensor, sd, cfg: dict, prefix: str = 'mod
         F = keep
 
 
+FP16_GROUPS = ('front', 'blockin', 'mid', 'x1', 'spec', 't', 'up1', 'up2', 'up3')
+
+
+def generator_forward_fp16_storage(x: Tensor, sd, cfg: dict, half=('front', 'blockin', 'mid', 'x1', 'spec', 't'), prefix: str = 'model.') -> Tensor:
+    """``generator_forward`` with a rounding to fp16 exactly where a LAMA_PREC_F16 run STORES an fp16 tensor in HBM (weights and all arithmetic
+    fp32: the path keeps hi + lo weight parts and accumulates in fp32) -- the yardstick of the fp16-activation path by tensor group:
+    ``front`` stem / down1 / down2 outputs; ``mid`` the (x_l | x_g) tensor between conv1 and conv2 of a resnet block (the residual stream is
+    fp32); ``x1`` SpectralTransform.conv1's output; ``spec`` both spectra of the FourierUnit; ``t`` = x1 + fu(x1); ``up1..3`` the outputs of the
+    three ConvTranspose2d + BN + ReLU; and ``blockin``: not a stored tensor but the READ of the fp32 residual stream by conv1 of every resnet
+    block -- LAMA_PREC_F16 spends one matrix-core operand on an activation, so the stream is rounded to fp16 while it is staged (the stream
+    itself, and the residual add, stay fp32).  Default = the layout since round 4 (the tail behind the blocks stays fp32 with the 3-term
+    split: FFCResNetGenerator.f16_fp32_tail)."""
+    half = set(half)
+
+    def r(t, group):
+        return t.half().float() if group in half else t
+
+    def fu(x, p):
+        b, c, h, w = x.shape
+        ff = torch.fft.rfftn(x, dim=(-2, -1), norm='ortho')
+        ff = torch.stack((ff.real, ff.imag), dim=-1).permute(0, 1, 4, 2, 3).contiguous().view(b, -1, h, w // 2 + 1)
+        ff = F.conv2d(r(ff, 'spec'), sd[p + '.conv_layer.weight'])
+        ff = r(torch.relu(_bn(ff, sd, p + '.bn')), 'spec')
+        ff = ff.view(b, -1, 2, h, w // 2 + 1).permute(0, 1, 3, 4, 2).contiguous()
+        return torch.fft.irfftn(torch.complex(ff[..., 0], ff[..., 1]), s=(h, w), dim=(-2, -1), norm='ortho')
+
+    def st(x, p, calib=None):
+        x = r(torch.relu(_bn(F.conv2d(x, sd[p + '.conv1.0.weight']), sd, p + '.conv1.1')), 'x1')
+        return F.conv2d(r(x + fu(x, p + '.fu'), 't'), sd[p + '.conv2.weight'])
+
+    global spectral_transform
+    keep = spectral_transform
+    spectral_transform = lambda x, sd_, p, calib=None: st(x, p)
+    try:
+        plan, n_up = layer_plan(cfg), 0
+        for i, L in enumerate(plan):
+            p, kind = f'{prefix}{i}', L['kind']
+            if kind == 'reflpad':
+                x = F.pad(x, (L['pad'],) * 4, mode='reflect')
+            elif kind == 'ffc_bn_act':
+                x_l, x_g = x if isinstance(x, tuple) else (x, 0)
+                x = ffc_bn_act(x_l, x_g, sd, p, L)
+                if not torch.is_tensor(x[1]):                 # stem / down1 / down2: local only
+                    x = (r(x[0], 'front'), x[1])
+            elif kind == 'resblock':
+                s = dict(k=3, stride=1, pad=1, ratio_gin=L['ratio_gin'], ratio_gout=L['ratio_gout'])
+                y_l, y_g = ffc_bn_act(r(x[0], 'blockin'), r(x[1], 'blockin'), sd, p + '.conv1', s)
+                y_l, y_g = ffc_bn_act(r(y_l, 'mid'), r(y_g, 'mid'), sd, p + '.conv2', s)
+                x = (x[0] + y_l, x[1] + y_g)
+            elif kind == 'concat':
+                x = torch.cat(x, dim=1) if torch.is_tensor(x[1]) else x[0]
+            elif kind == 'convT':
+                x = F.conv_transpose2d(x, sd[p + '.weight'], sd[p + '.bias'], stride=2, padding=1, output_padding=1)
+            elif kind == 'bn':
+                x = _bn(x, sd, p)
+            elif kind == 'relu':
+                n_up += 1
+                x = r(torch.relu(x), f'up{n_up}')
+            elif kind == 'conv_out':
+                x = F.conv2d(x, sd[p + '.weight'], sd[p + '.bias'])
+            elif kind == 'act':
+                x = torch.sigmoid(x) if L['act'] == 'sigmoid' else torch.tanh(x)
+            else:
+                raise ValueError(kind)
+        return x
+    finally:
+        spectral_transform = keep
+
+
 def training_module_forward(batch: dict, sd, cfg: dict, prefix: str = 'generator.model.') -> dict:
     """DefaultInpaintingTrainingModule.forward, eval path: trainers/default.py:56-59,67-71,82-86."""
     img, mask = batch['image'], batch['mask']

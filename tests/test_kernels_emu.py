@@ -475,6 +475,7 @@ WINO_CASES = [
     dict(cin=32, cout=128, H=16, W=32, B=1, act=1, bias=True, resid=True, scale=True),
     dict(cin=64, cout=128, H=16, W=64, B=2, act=0, bias=False, resid=False, scale=False),
     dict(cin=32, cout=256, H=8, W=64, B=1, act=1, bias=True, resid=False, scale=True),
+    dict(cin=128, cout=128, H=16, W=32, B=1, act=1, bias=True, resid=True, scale=True),       # 8 (band, xi) units: the input channels dealt to four workgroups each (split-K of small launches)
 ]
 
 
