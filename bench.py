@@ -20,7 +20,7 @@ The JSON line also carries
                    `peak_sustained` is what THIS box sustains on random operands with nothing but MFMAs in flight (measured
                    live through the profiling build's lama_debug_mfma_peak: the part is power limited) and
                    `frac_of_sustained` prices the kernel against that.  `traffic` comes from the committed PMC passes
-                   (profiles/r03_pmc.json; a live bench run cannot host the profiler).
+                   (profiles/r04_pmc.json: in-pipeline counter passes; a live bench run cannot host the profiler).
   roofline_ffc  -- the unit BASELINE.json names: FourierUnit forward (rfft2 -> spectral 1x1+BN+ReLU ->
                    irfft2 + residual), algorithmic bytes / time against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (CPU restatement of the reference, same torch-CPU primitives) timed on
@@ -112,7 +112,7 @@ class KernelTimer:
 
     def __init__(self, lib):
         self.lib, self.records, self.on = lib, {}, False
-        self.flops, self.bytes = {}, {}
+        self.flops, self.bytes, self._nb = {}, {}, {}
         self._conv, self._fu, self._wino = lib.conv2d, lib.fourier_unit, lib.winograd_conv3x3
         lib.conv2d, lib.fourier_unit, lib.winograd_conv3x3 = self.conv2d, self.fourier_unit, self.winograd_conv3x3
 
@@ -144,7 +144,10 @@ class KernelTimer:
             key += f'+next_conv1x1_cout{f1[2].C}'
             flops += 2.0 * batch * y.H * y.W * f1[2].C * y.C
             nbytes += 4.0 * batch * f1[2].C * y.H * y.W
-        self.flops[key], self.bytes[key] = flops, nbytes
+        # (the same key is launched with and without a residual operand -- first / second layer of a block: the bytes are the mean over the launches)
+        n, mean = self._nb.get(key, (0, 0.0))
+        self._nb[key] = (n + 1, (mean * n + nbytes) / (n + 1))
+        self.flops[key], self.bytes[key] = flops, self._nb[key][1]
         return self._timed(key, self._conv, x, w_packed, y, batch, k, *a, **kw)
 
     def fourier_unit(self, x, *a, **kw):
@@ -618,7 +621,7 @@ def main():
                         measured='HIP events around every launch in 3 eager steps after the timed region, on the launch stream, in the launch order of '
                                  'the timed region (round 3: ONE stream for plans whose residual blocks take the Winograd local conv -- every kernel runs '
                                  'alone on the GPU in the timed region too; conv1 of the next layer rides in this launch when the key says +next_conv1x1).  '
-                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r03_kernel_stats.csv',
+                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r04_kernel_stats.csv',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '

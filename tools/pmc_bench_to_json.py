@@ -13,15 +13,19 @@ B, H = 8, 64
 MB = lambda *ch: int(4 * B * H * H * sum(ch))        # fp32 [8, ch, 64, 64] tensors
 KEYS = [   # (bench key, [kernel-name regex ...] summed, algorithmic bytes, note)
     ('conv3x3_cin128_cout384_64x64+1x1_cin192+next_conv1x1_cout192', [r'conv_wr_kernel_f16x3<9, 2, 1, 4, 12, 1, 0, 2, (false, ){5}2, true>'],
-     MB(128, 192, 384, 384, 192) + 2064384 + 294912, 'global 3x3 + 1x1 over t + residual + fused conv1 of the next layer: x_l, t, residual in; x_g, x1 out; weights once'),
+     (18 * MB(128, 192, 384, 384, 192) + 17 * MB(128, 192, 384, 192)) // 35 + 2064384 + 294912,
+     'global 3x3 + 1x1 over t (+ residual in the 18 second layers of a block, not in the 17 first ones: the average of the 35 launches of a step) + fused '
+     'conv1 of the next layer: x_l, t, (residual) in; x_g, x1 out; weights once'),
     ('conv3x3_cin128_cout384_64x64+1x1_cin192', [r'conv_wr_kernel_f16x3<9, 2, 1, 4, 12, 1, 0, 2, (false, ){5}2, false>'],
-     MB(128, 192, 384) + 2064384, 'the same launch without a next layer (last block) / without a residual (first FFC layer of a block)'),
-    ('conv3x3_cin512_cout128_64x64', [r'wino_gemm_kernel', r'wino_out_kernel'], MB(512, 128, 128) + 2359296, 'local 3x3 conv as Winograd F(2x2,3x3): both launches'),
+     MB(128, 192, 384, 384) + 2064384, 'the same launch without a next layer (the last block): x_l, t, residual in; x_g out'),
+    ('conv3x3_cin512_cout128_64x64', [r'wino_gemm_kernel', r'wino_out_kernel'], (18 * MB(512, 128, 128) + 18 * MB(512, 128)) // 36 + 2359296,
+     'local 3x3 conv as Winograd F(2x2,3x3): both launches (residual in every second layer)'),
     ('conv1x1_cin384_cout384_64x33', [r'gemm1x1_wk_kernel'], int(2 * 4 * B * 384 * 64 * 33 + 589824), 'spectral 1x1 of the FourierUnit'),
     ('conv1x1_cin384_cout192_64x64', [r'gemm1x1_w4_kernel_f16x3<6, 2, false'], MB(384, 192) + 294912, 'SpectralTransform.conv1 as a launch of its own (first residual layer only)'),
-    ('rfft2_192x64x64', [r'rfft2_ip64_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33), 'rfft2 of 8 x 192 planes of 64 x 64'),
+    ('rfft2_192x64x64', [r'^void rfft2_ip64_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33), 'rfft2 of 8 x 192 planes of 64 x 64'),
     ('irfft2_192x64x64', [r'^void irfft2_ip64_kernel'], int(2 * MB(192) + 4 * B * 384 * 64 * 33), 'irfft2 + the x + fu(x) add'),
-    ('conv3x3T_cin128_cout64_512x512', [r'convt2_kernel.*g=131072$'], int(4 * B * (128 * 256 * 256 + 64 * 512 * 512)), 'up3'),
+    ('conv3x3T_up1_up2_up3_average', [r'convt2_kernel'], int(4 * B * (512 * 64 * 64 + 256 * 128 * 128 + 256 * 128 * 128 + 128 * 256 * 256 + 128 * 256 * 256 + 64 * 512 * 512) / 3),
+     'the three ConvTranspose2d launches (one persistent grid size: the profiler cannot tell them apart): average of up1, up2, up3'),
     ('conv7x7_cin64_cout3_512x512', [r'head7_ws_kernel'], int(4 * B * 67 * 512 * 512), 'head'),
     ('conv7x7_cin4_cout64_512x512', [r'stem7_ws_kernel'], int(4 * B * 68 * 512 * 512), 'stem'),
 ]
