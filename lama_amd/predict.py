@@ -14,7 +14,7 @@ is ``<mask path up to '_mask'><img_suffix>`` (``evaluation/data.py:59-62``), the
 What differs from the reference's batch-1 Python loop: images are padded to ``pad_out_to_modulo`` and *bucketed by
 padded shape*, each bucket is cut into batches, batches are dealt round-robin to the ranks (one process per GPU,
 weights replicated, no communication during compute), the u8 HWC results are produced on the device and the only
-collective is one all-gather of those output images per round (RCCL over xGMI on GPUs, gloo in the CPU tests); rank 0
+collective is one gather of those output images to rank 0 per round (RCCL over xGMI on GPUs, gloo in the CPU tests); rank 0
 writes the PNGs on a thread pool so file IO overlaps the next round's compute.
 """
 from __future__ import annotations

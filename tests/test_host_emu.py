@@ -173,6 +173,39 @@ def test_f16_split_overflow_falls_back_to_bf16x3():
     assert float((y1 - y0).abs().max()) < 1e-3, float((y1 - y0).abs().max())
 
 
+def test_deferred_range_check_has_no_read_back_per_forward():
+    """Round 4: ``defer_range_check`` -- the forward does not read the range flag back (no host synchronisation per step); the flag stays
+    raised on the device across forwards and ``check_range()`` reports it at the caller's synchronisation point: False = the results since
+    the last check are void and the generator is on the bf16 split now; LamaRangeError without ``auto_fallback``."""
+    from lama_amd import _lib as L
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = O.make_synthetic_state_dict(cfg, seed=5, calib_hw=32)
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen.set_exec(F._Exec(emu_lib()))
+    gen.defer_range_check = True
+    batch = O.make_synthetic_batch(1, 64, 64, seed=2)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    y0 = gen(x)
+    assert gen.check_range() is True and gen.precision == L.PREC_F16X3
+    xb = x.clone()
+    xb[0, 1, 20:24, 30:34] = 3.0e5
+    gen(xb)                                                   # no exception, no precision switch: nobody has looked yet
+    assert gen.precision == L.PREC_F16X3
+    gen(x)                                                    # ... and an in-range forward afterwards does not clear the flag
+    gen.auto_fallback = False
+    with pytest.raises(L.LamaRangeError):
+        gen.check_range()
+    assert gen.check_range() is True                          # reading clears it
+    gen.auto_fallback = True
+    gen(xb)
+    with pytest.warns(UserWarning, match='bf16'):
+        assert gen.check_range() is False
+    assert gen.precision == L.PREC_BF16X3
+    y1 = gen(x)                                               # the re-run the caller owes, on the bf16 split
+    assert gen.check_range() is True and float((y1 - y0).abs().max()) < 1e-3
+
+
 def test_generator_fp16_activation_path(small):
     """BASELINE configs[2] "fp16" = PREC_F16: fp16 activations in memory from the stem's output through the resnet blocks (fp32 residual stream;
     round 4: fp32 tail behind the blocks), weights as hi + lo fp16 parts (two MFMA products per MAC since round 3), fp32 accumulation.  Tolerance: 5e-3 max-abs on the sigmoid output at this size and no
