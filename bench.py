@@ -488,6 +488,8 @@ def main():
     # No host synchronisation inside a step: the fp16 split's range flag is not read back per forward (generator.defer_range_check) but
     # ONCE, after the closing barrier and still inside the timed region -- a raised flag would void the run (checked below).
     model.generator.defer_range_check = True
+    if 'LAMA_INPLACE' in os.environ:          # same-box A/B of the in-place residual state / t over x1 (tools/session.sh ab:LAMA_INPLACE=0,1)
+        model.generator.inplace_residual = model.generator.alias_t = bool(int(os.environ['LAMA_INPLACE']))
     for _ in range(args.warmup):
         step()
     barrier()

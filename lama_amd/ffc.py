@@ -547,13 +547,15 @@ class FFC(_HipModule):
         Wo = (W + 2 * pad - self.kernel_size) // self.stride + 1
         return (B, self.out_cl + self.out_cg, Ho, Wo)
 
-    def make_scratch(self, src_shape, device) -> Optional[dict]:
+    def make_scratch(self, src_shape, device, alias_t: bool = False) -> Optional[dict]:
+        """``alias_t``: t = x1 + fu(x1) is written over x1 (irfft2 reads the residual element where it writes; the global-branch launch reads t
+        for the pixels of a tile before its epilogue writes the NEXT layer's x1 for the same pixels)."""
         if self.in_cg == 0:
             return None
         B, _, H, W = src_shape
         half = self.convg2g.conv2.in_channels
         x1 = torch.empty(B, half, H, W, device=device, dtype=_act_dtype(self.precision))
-        sc = dict(x1=x1, t=torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
+        sc = dict(x1=x1, t=x1 if alias_t else torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
         lib = self._exec.lib
         if (self._exec.winograd and self.kernel_size == 3 and self.stride == 1 and self.padding == 1 and self.out_cl
                 and lib.winograd_supported(self.out_cl, self.in_cl + self.in_cg, H, W, self.precision)):
@@ -623,8 +625,8 @@ class FFC_BN_ACT(_HipModule):
     def out_shape(self, src_shape, extra_pad: int = 0):
         return self.ffc.out_shape(src_shape, extra_pad)
 
-    def make_scratch(self, src_shape, device) -> Optional[dict]:
-        return self.ffc.make_scratch(src_shape, device)
+    def make_scratch(self, src_shape, device, alias_t: bool = False) -> Optional[dict]:
+        return self.ffc.make_scratch(src_shape, device, alias_t)
 
     def forward(self, x, extra_pad: int = 0):
         x_l, x_g = x if type(x) is tuple else (x, 0)
@@ -918,6 +920,10 @@ class FFCResNetGenerator(_HipModule):
         # are largest behind the 18 blocks).  On the GPU at 4 x 1024^2: 1.68e-2 -> 1.19e-2 max-abs for 218 -> 210 images/s.
         # False = the round-3 layout (everything between stem and head fp16).
         self.f16_fp32_tail = True
+        # working set of a residual layer (8 x 512^2: three 67 MB state buffers + x1, t, two spectra, the Winograd partial sums = 337 MB against
+        # 256 MB of Infinity Cache): the block output in place of its input, t = x1 + fu(x1) in place of x1
+        self.inplace_residual = True
+        self.alias_t = True
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
@@ -971,9 +977,17 @@ class FFCResNetGenerator(_HipModule):
                 cur, cur_shape, pad_pending = dst, shp, 0
             elif isinstance(lay, FFCResnetBlock):
                 if scratch is None:
-                    scratch = lay.conv1.make_scratch(cur_shape, device)
-                    new('rt', cur_shape); new('rA', cur_shape, torch.float32); new('rB', cur_shape, torch.float32)
-                dst = 'rA' if cur != 'rA' else 'rB'
+                    scratch = lay.conv1.make_scratch(cur_shape, device, alias_t=self.alias_t)
+                    new('rt', cur_shape)
+                # the block's output IN PLACE of its input (round 4): the second layer reads the input only as its residual operand, element
+                # by element where it writes (Winograd out kernel, global-branch epilogue), so the 18 blocks walk on TWO state buffers
+                # instead of three: 67 MB less working set per layer at 8 x 512^2
+                if self.inplace_residual and cur != 'in' and bufs[cur].dtype == torch.float32:
+                    dst = cur
+                else:
+                    dst = 'rA' if cur != 'rA' else 'rB'
+                    if dst not in bufs:
+                        new(dst, cur_shape, torch.float32)
                 steps.append(('res', lay, cur, 'rt', dst))
                 cur = dst
             elif isinstance(lay, ConcatTupleLayer):
