@@ -490,6 +490,8 @@ def main():
     model.generator.defer_range_check = True
     if 'LAMA_INPLACE' in os.environ:          # same-box A/B of the in-place residual state / t over x1 (tools/session.sh ab:LAMA_INPLACE=0,1)
         model.generator.inplace_residual = model.generator.alias_t = bool(int(os.environ['LAMA_INPLACE']))
+    if 'LAMA_ALIAS_WINO' in os.environ:       # ... of the Winograd partial sums in the FourierUnit's (dead) spectra
+        model.generator.alias_wino = bool(int(os.environ['LAMA_ALIAS_WINO']))
     for _ in range(args.warmup):
         step()
     barrier()

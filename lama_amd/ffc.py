@@ -924,6 +924,7 @@ class FFCResNetGenerator(_HipModule):
         # 256 MB of Infinity Cache): the block output in place of its input, t = x1 + fu(x1) in place of x1
         self.inplace_residual = True
         self.alias_t = True
+        self.alias_wino = True
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
@@ -1031,6 +1032,14 @@ class FFCResNetGenerator(_HipModule):
         if scratch and scratch.get('wino') is not None and not wino:
             scratch['wino'] = None                   # 33 MB at 8 x 64 x 64 that no launch would read
         serial = wino and self.serial_with_winograd
+        if serial and self.alias_wino:
+            # one-stream order: the FourierUnit's spectra (rfft2 -> GEMM -> irfft2) are dead when the Winograd launches start and the
+            # Winograd partial sums are dead when the next layer's rfft2 starts: one allocation for both (8 x 512^2: 33.5 of 52 MB shared)
+            ws, wn = scratch['ws'], scratch['wino']
+            if wn.numel() <= ws.numel():
+                scratch['wino'] = ws[:wn.numel()]
+            else:
+                scratch['ws'] = wn[:ws.numel()]
         side = torch.cuda.Stream(device=device) if (self.overlap_streams and not serial and torch.device(device).type == 'cuda') else None
         return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None, side=side,
                     fuse=self.fuse_conv1 or (serial and self.fuse_conv1 is not False and self.fuse_conv1_serial))
