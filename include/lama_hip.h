@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 107
+#define LAMA_HIP_VERSION 108
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -207,6 +207,22 @@ int lama_add_fwd(void* stream, const lama_tensor* a, const lama_tensor* b, const
  * (+ addend, optional): every padded position is added onto the input pixel it mirrors. */
 int lama_reflect_pad_bwd(void* stream, const lama_tensor* gp, const lama_tensor* addend, int32_t pad, const lama_tensor* g,
                          int32_t batch);
+/* (v108) the same adjoint fused with what the reverse pass does to its result: s = fold(gp) [+ add1] [+ add2]; g = s (optional, may be
+ * add2 itself); gm = s * act'(mask_y) (optional).  add1: the 1x1 path into the same tensor (SpectralTransform.conv1, ffc.py:158), add2: the
+ * identity path of the resnet block (ffc.py:288), mask_y: the taped output of the layer upstream (ffc.py:253-254).  Replaces autograd's
+ * separate AddBackward / ReluBackward passes of refinement.py:163; at least one of g, gm. */
+int lama_reflect_pad_bwd_fused(void* stream, const lama_tensor* gp, const lama_tensor* add1, const lama_tensor* add2, int32_t pad,
+                               const lama_tensor* mask_y, int32_t act, const lama_tensor* g, const lama_tensor* gm, int32_t batch,
+                               const float* ring);
+/* (v108) the data gradient of a reflect-padded 3x3 conv (ffc.py:188-196) WITHOUT its padded plane: the interior H x W of the zero-padded
+ * correlation is a zero-pad-1 conv of the output gradient (lama_conv2d_fwd / lama_winograd_conv3x3_fwd with LAMA_PAD_ZERO, pad 1) and the
+ * one-pixel frame around it -- rows y = -1, H (x = -1..W), columns x = -1, W (y = 0..H-1) -- is computed here, exact fp32:
+ *   ring [batch][cout][2 (W + 2) + 2 H] (top, bottom, left, right; lama_dgrad_ring_bytes),
+ *   w_ring [4][cin][3][cout] fp32 = the dgrad weights w'[cout][cin][3][3] (flipped, transposed) as  top: w'[o][c][2][k], bottom: w'[o][c][0][k],
+ *   left: w'[o][c][k][2], right: w'[o][c][k][0];  cout % 128 == 0, cin % 64 == 0.
+ * lama_reflect_pad_bwd_fused with ring != NULL then takes gp = the interior [B,C,H,W] (pad must be 1). */
+size_t lama_dgrad_ring_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W);
+int lama_dgrad_ring_fwd(void* stream, const lama_tensor* g, const float* w_ring, int32_t cout, float* ring, int32_t batch);
 /* kornia.filters.gaussian_blur2d(x, (5,5), (1.0,1.0)) [border reflect] of the top-left crop [0:y.H, 0:y.W] of x
  * (refinement.py:24,52,149), and its adjoint (gx is zero outside the crop). */
 int lama_gauss5_fwd(void* stream, const lama_tensor* x, const lama_tensor* y, int32_t batch);

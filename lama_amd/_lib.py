@@ -17,7 +17,7 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 CONV_COOPERATIVE = 1
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 107      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 108      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -112,7 +112,9 @@ class LamaLib:
         L.lama_reflect_pad_fwd.argtypes = [vp, T, i32, T, i32]
         f32, dp = C.c_float, C.POINTER(C.c_double)
         for name, args in (('lama_act_bwd', [vp, T, T, i32, T, i32]), ('lama_add_fwd', [vp, T, T, T, i32]),
-                           ('lama_reflect_pad_bwd', [vp, T, T, i32, T, i32]), ('lama_gauss5_fwd', [vp, T, T, i32]),
+                           ('lama_reflect_pad_bwd', [vp, T, T, i32, T, i32]), ('lama_reflect_pad_bwd_fused', [vp, T, T, T, i32, T, i32, T, T, i32, vp]),
+                           ('lama_dgrad_ring_fwd', [vp, T, vp, i32, vp, i32]),
+                           ('lama_gauss5_fwd', [vp, T, T, i32]),
                            ('lama_gauss5_bwd', [vp, T, T, i32]), ('lama_bilinear_fwd', [vp, T, T, i32]),
                            ('lama_bilinear_bwd', [vp, T, T, i32]), ('lama_threshold_fwd', [vp, T, f32, T, i32]),
                            ('lama_erode_fwd', [vp, T, vp, i32, i32, f32, T, i32]),
@@ -121,6 +123,7 @@ class LamaLib:
                            ('lama_adam_step', [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32])):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = C.c_int, args
+        L.lama_dgrad_ring_bytes.restype, L.lama_dgrad_ring_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
         L.lama_ssim_workspace_bytes.restype, L.lama_ssim_workspace_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
         L.lama_ssim_fwd.restype, L.lama_ssim_fwd.argtypes = C.c_int, [vp, T, T, i32, i32, C.POINTER(C.c_float), vp, vp, C.c_size_t]
         L.lama_fuse1_channel_order.restype, L.lama_fuse1_channel_order.argtypes = None, [C.POINTER(C.c_int32)]
@@ -230,11 +233,11 @@ class LamaLib:
 
     def winograd_conv3x3(self, x: Tensor4, w_packed: torch.Tensor, y: Tensor4, batch: int, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
                          act: int = ACT_NONE, resid: Optional[Tensor4] = None, precision: int = PREC_F16X3, stream: int = 0,
-                         range_flag: Optional[torch.Tensor] = None):
+                         range_flag: Optional[torch.Tensor] = None, pad_mode: int = PAD_REFLECT):
         a = Conv2dArgs()
         a.x, a.w_packed = x, w_packed.data_ptr()
         a.kh = a.kw = 3
-        a.stride, a.pad, a.pad_mode, a.transposed = 1, 1, PAD_REFLECT, 0
+        a.stride, a.pad, a.pad_mode, a.transposed = 1, 1, pad_mode, 0
         a.bias = None if bias is None else bias.data_ptr()
         a.act = act
         if resid is not None:
@@ -299,6 +302,28 @@ class LamaLib:
 
     def add(self, a: Tensor4, b: Tensor4, out: Tensor4, batch: int, stream: int = 0):
         self.check(self._l.lama_add_fwd(stream, C.byref(a), C.byref(b), C.byref(out), batch), 'lama_add_fwd')
+
+    def reflect_pad_bwd_fused(self, gp: Tensor4, add1: Optional[Tensor4], add2: Optional[Tensor4], pad: int, mask_y: Optional[Tensor4], act: int,
+                              g: Optional[Tensor4], gm: Optional[Tensor4], batch: int, stream: int = 0, ring: Optional[torch.Tensor] = None):
+        """s = fold(gp) [+ add1] [+ add2]; g = s; gm = s * act'(mask_y) -- one pass (include/lama_hip.h, v108).  With ``ring`` (dgrad_ring), gp
+        is the interior [B,C,H,W] of the padded plane."""
+        r = lambda t: None if t is None else C.byref(t)    # noqa: E731
+        self.check(self._l.lama_reflect_pad_bwd_fused(stream, C.byref(gp), r(add1), r(add2), pad, r(mask_y), act, r(g), r(gm), batch,
+                                                      None if ring is None else ring.data_ptr()), 'lama_reflect_pad_bwd_fused')
+
+    def dgrad_ring_bytes(self, b: int, cout: int, h: int, w: int) -> int:
+        return int(self._l.lama_dgrad_ring_bytes(b, cout, h, w))
+
+    @staticmethod
+    def dgrad_ring_weight(w_dgrad: torch.Tensor) -> torch.Tensor:
+        """w' [cout, cin, 3, 3] (the flipped, transposed weights of a 3x3 dgrad conv) -> [4][cin][3][cout] fp32 (include/lama_hip.h)."""
+        wt = w_dgrad.detach().float().permute(1, 2, 3, 0)            # [cin][ky][kx][cout]
+        return torch.stack([wt[:, 2], wt[:, 0], wt[:, :, 2], wt[:, :, 0]], 0).contiguous()
+
+    def dgrad_ring(self, g: Tensor4, w_ring: torch.Tensor, cout: int, ring: torch.Tensor, batch: int, stream: int = 0):
+        if ring.numel() * 4 < self.dgrad_ring_bytes(batch, cout, g.H, g.W) or tuple(w_ring.shape) != (4, g.C, 3, cout):
+            raise LamaError('dgrad_ring: ring / weight buffer does not match the launch', ERR_BAD_ARG)
+        self.check(self._l.lama_dgrad_ring_fwd(stream, C.byref(g), w_ring.data_ptr(), cout, ring.data_ptr(), batch), 'lama_dgrad_ring_fwd')
 
     def reflect_pad_bwd(self, gp: Tensor4, addend: Optional[Tensor4], pad: int, g: Tensor4, batch: int, stream: int = 0):
         self.check(self._l.lama_reflect_pad_bwd(stream, C.byref(gp), None if addend is None else C.byref(addend), pad, C.byref(g), batch),

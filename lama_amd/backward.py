@@ -73,8 +73,20 @@ class _FFCLayerTape:
         ex.lib.rfft2(L.view(x1), L.view(sh['s1']), B, sh['fftws'], st)
         ex.conv2d(L.view(sh['s1']), fuw, L.view(s2), B, 1, bias=fub, act=L.ACT_RELU, precision=prec, stream=st)
         ex.lib.irfft2(L.view(s2), L.view(x1), L.view(sh['t']), B, sh['fftws'], st)
-        ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, 1, L.PAD_REFLECT, False, pk['b_l'], lay._act, None,
-                  precision=prec, stream=st)
+        done = False
+        if sh.get('wino') is not None and 'w_lout_wino' in pk and ex.winograd:
+            # the local 3x3 as Winograd F(2x2, 3x3), as in the predict path (FFC.launch); shapes / views the entry does not take: direct kernel
+            try:
+                ex.winograd_conv3x3(L.view(src), pk['w_lout_wino'], L.view(dst, 0, ocl), B, sh['wino'], pk['b_l'], lay._act, None,
+                                    precision=prec, stream=st)
+                done = True
+            except LamaError as e:
+                if e.code != L.ERR_UNSUPPORTED:
+                    raise
+                sh['wino'] = None
+        if not done:
+            ex.conv2d(L.view(src), pk['w_lout'], L.view(dst, 0, ocl), B, 3, 1, 1, L.PAD_REFLECT, False, pk['b_l'], lay._act, None,
+                      precision=prec, stream=st)
         ex.conv2d(L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, 1, L.PAD_REFLECT, False, pk['b_g'], lay._act, None,
                   x2=L.view(sh['t']), w2_packed=sp['w2'], precision=prec, stream=st)
 
@@ -91,7 +103,17 @@ class _FFCLayerTape:
         sfu, _ = F._bn_fold(st.fu.bn)
         bw = {}
         # d x_l <- [g_l | g_g] through convl2l / convl2g (one conv over the 512 gradient channels)
-        bw['wd_l'] = lib.pack_conv_weight(torch.cat([_tflip(f.convl2l.weight, sl), _tflip(f.convl2g.weight, sg)], dim=1), None, precision=prec)
+        wd_l = torch.cat([_tflip(f.convl2l.weight, sl), _tflip(f.convl2g.weight, sg)], dim=1)
+        bw['wd_l'] = lib.pack_conv_weight(wd_l, None, precision=prec)
+        # round 4: the same dgrad without its padded plane -- interior as Winograd F(2x2, 3x3) with zero padding, frame by lama_dgrad_ring_fwd
+        # (the planes decide per call whether the Winograd entry takes them: _FFCLayerTape.backward)
+        if self.ex.winograd and prec in (L.PREC_BF16X3, L.PREC_F16X3) and wd_l.shape[0] % 128 == 0 and wd_l.shape[1] % 32 == 0:
+            try:
+                bw['wd_l_wino'] = lib.pack_winograd_weight(wd_l, None, prec)
+                bw['wr_l'] = lib.dgrad_ring_weight(wd_l).to(wd_l.device)
+            except LamaError as e:
+                if e.code != L.ERR_UNSUPPORTED:
+                    raise
         bw['wd_g2l'] = lib.pack_conv_weight(_tflip(f.convg2l.weight, sl), None, precision=prec)          # d x_g <- g_l
         bw['wd_2'] = lib.pack_conv_weight(_tflip(st.conv2.weight, sg), None, precision=prec)               # d t <- g_g
         bw['wd_fu'] = lib.pack_conv_weight(_tflip(st.fu.conv_layer.weight, sfu), None, precision=prec)     # spectral 1x1, transposed
@@ -99,20 +121,38 @@ class _FFCLayerTape:
         self._bw = bw
         return bw
 
-    def backward(self, g_dst: torch.Tensor, g_src: torch.Tensor, tape: dict, sh: dict):
-        """g_dst [B,512,H,W] = d loss / d (layer output) -> g_src = d loss / d (layer input)."""
+    def backward(self, gm: torch.Tensor, tape: dict, sh: dict, g_src: Optional[torch.Tensor], gm_src: Optional[torch.Tensor] = None,
+                 identity: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None):
+        """gm [B,512,H,W] = d loss / d (layer output) ALREADY multiplied by the layer's own activation derivative (the step upstream in
+        the reverse order wrote it: round 4, lama_reflect_pad_bwd_fused) -> s = d loss / d (layer input) [+ identity];
+        ``g_src`` <- s (may be ``identity`` itself), ``gm_src`` <- s * relu'(mask) for the layer whose taped output ``mask`` is."""
         lay, ex, prec = self.lay, self.ex, self.bprec
         f = lay.ffc
         bw = self._pack_bwd()
-        B = g_dst.shape[0]
-        st = ex.stream(g_dst)
+        B = gm.shape[0]
+        st = ex.stream(gm)
         lib = ex.lib
         cl, cg, ocl, ocg = f.in_cl, f.in_cg, f.out_cl, f.out_cg
-        gm = sh['gm']
-        lib.act_bwd(L.view(g_dst), L.view(tape['out']), lay._act, L.view(gm), B, st)
+        v = lambda t, c0, n: None if t is None else L.view(t, c0, n)     # noqa: E731
         # local input
-        lib.conv2d(L.view(gm), bw['wd_l'], L.view(sh['gp_l']), B, 3, 1, 2, L.PAD_ZERO, False, None, L.ACT_NONE, precision=prec, stream=st)
-        lib.reflect_pad_bwd(L.view(sh['gp_l']), None, 1, L.view(g_src, 0, cl), B, st)
+        done = False
+        if 'wd_l_wino' in bw and sh.get('wino_b') is not None:
+            try:
+                lib.winograd_conv3x3(L.view(gm), bw['wd_l_wino'], L.view(sh['gi_l']), B, sh['wino_b'], None, L.ACT_NONE, None, precision=prec,
+                                     stream=st, pad_mode=L.PAD_ZERO)
+                done = True
+            except LamaError as e:
+                if e.code != L.ERR_UNSUPPORTED:
+                    raise
+                sh['wino_b'] = None
+        if done:
+            lib.dgrad_ring(L.view(gm), bw['wr_l'], cl, sh['ring_l'], B, st)
+            lib.reflect_pad_bwd_fused(L.view(sh['gi_l']), None, v(identity, 0, cl), 1, v(mask, 0, cl), L.ACT_RELU, v(g_src, 0, cl),
+                                      v(gm_src, 0, cl), B, st, ring=sh['ring_l'])
+        else:
+            lib.conv2d(L.view(gm), bw['wd_l'], L.view(sh['gp_l']), B, 3, 1, 2, L.PAD_ZERO, False, None, L.ACT_NONE, precision=prec, stream=st)
+            lib.reflect_pad_bwd_fused(L.view(sh['gp_l']), None, v(identity, 0, cl), 1, v(mask, 0, cl), L.ACT_RELU, v(g_src, 0, cl),
+                                      v(gm_src, 0, cl), B, st)
         # spectral branch: t = x1 + fu(x1), out_g += conv2(t)
         lib.conv2d(L.view(gm, ocl, ocg), bw['wd_2'], L.view(sh['g_t']), B, 1, precision=prec, stream=st)
         lib.rfft2(L.view(sh['g_t']), L.view(sh['s1']), B, sh['fftws'], st)
@@ -123,7 +163,8 @@ class _FFCLayerTape:
         # global input: through convg2l (3x3) and through conv1 (1x1)
         lib.conv2d(L.view(gm, 0, ocl), bw['wd_g2l'], L.view(sh['gp_g']), B, 3, 1, 2, L.PAD_ZERO, False, None, L.ACT_NONE, precision=prec, stream=st)
         lib.conv2d(L.view(sh['g_x1']), bw['wd_1'], L.view(sh['g1']), B, 1, precision=prec, stream=st)
-        lib.reflect_pad_bwd(L.view(sh['gp_g']), L.view(sh['g1']), 1, L.view(g_src, cl, cg), B, st)
+        lib.reflect_pad_bwd_fused(L.view(sh['gp_g']), L.view(sh['g1']), v(identity, cl, cg), 1, v(mask, cl, cg), L.ACT_RELU, v(g_src, cl, cg),
+                                  v(gm_src, cl, cg), B, st)
 
 
 class RearPass:
@@ -179,13 +220,25 @@ class RearPass:
         wf = W // 2 + 1
         e = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)    # noqa: E731
         nws = self.ex.lib.fft_workspace_bytes(B, half, H, W)
-        sh = dict(s1=e(B, 2 * half, H, wf), s3=e(B, 2 * half, H, wf), t=e(B, half, H, W), gm=e(B, Cn, H, W),
-                  fftws=(e(nws // 4 + 1) if nws else None),
+        lib = self.ex.lib
+        nwino = 0
+        if self.ex.winograd and lib.winograd_supported(f0.out_cl, f0.in_cl + f0.in_cg, H, W, self.gen.precision):
+            nwino = lib.winograd_workspace_bytes(B, f0.out_cl, H, W)
+        sh = dict(s1=e(B, 2 * half, H, wf), s3=e(B, 2 * half, H, wf), t=e(B, half, H, W),
+                  fftws=(e(nws // 4 + 1) if nws else None), wino=(e(nwino // 4) if nwino else None),
+                  wino_b=None, gi_l=None, ring_l=None,
                   gp_l=e(B, f0.in_cl, H + 2, W + 2), gp_g=e(B, f0.in_cg, H + 2, W + 2), g_t=e(B, half, H, W), g_x1=e(B, half, H, W),
                   g1=e(B, f0.in_cg, H, W))
+        if (self.ex.winograd and self.bprec in (L.PREC_BF16X3, L.PREC_F16X3) and f0.in_cl % 128 == 0
+                and lib.winograd_supported(f0.in_cl, f0.out_cl + f0.out_cg, H, W, self.bprec)):
+            # the dgrad into x_l as Winograd interior + frame (its own workspace: gm of the layer is live while the forward one is not, but
+            # the split-K factor differs with the channel counts)
+            sh['wino_b'] = e(lib.winograd_workspace_bytes(B, f0.in_cl, H, W) // 4)
+            sh['gi_l'] = e(B, f0.in_cl, H, W)
+            sh['ring_l'] = e(lib.dgrad_ring_bytes(B, f0.in_cl, H, W) // 4)
         tapes = [dict(c1=t1.alloc(B, H, W, dev), c2=t2.alloc(B, H, W, dev)) for _, t1, t2 in self.blocks]
         state = [e(B, Cn, H, W) for _ in range(2)]                       # block outputs ping-pong (the reverse pass does not need them)
-        gst = [e(B, Cn, H, W) for _ in range(3)]
+        gst = [e(B, Cn, H, W) for _ in range(3)]                         # g (in place), gm of the second / first layer of a block
         ups, h, w, c = [], H, W, Cn
         for up, bn in self.ups:
             h, w, c = 2 * h, 2 * w, up.out_channels
@@ -244,29 +297,43 @@ class RearPass:
         k = conv.kernel_size[0]
         lib.conv2d(L.view(hd['g1']), self._bw_head, L.view(hd['gp']), B, k, 1, k - 1, L.PAD_ZERO, False, None, L.ACT_NONE, precision=prec, stream=st)
         g = p['ups'][-1]['g'] if self.ups else p['gst'][0]
-        lib.reflect_pad_bwd(L.view(hd['gp']), None, pad, L.view(g), B, st)
+        # the head's fold writes the gradient already multiplied by the ReLU mask of the last upsampling layer (one pass less over the
+        # largest tensor of the network); with the debug taps on, the two steps stay apart
+        masked = bool(self.ups) and self.debug is None
+        if masked:
+            lib.reflect_pad_bwd_fused(L.view(hd['gp']), None, None, pad, L.view(p['ups'][-1]['y']), L.ACT_RELU, None, L.view(g), B, st)
+        else:
+            lib.reflect_pad_bwd(L.view(hd['gp']), None, pad, L.view(g), B, st)
         if self.debug is not None:
             self.debug['head_in'] = g.clone()
         for ui in range(len(self.ups) - 1, -1, -1):
             up, bn = self.ups[ui]
             ub = p['ups'][ui]
-            lib.act_bwd(L.view(g), L.view(ub['y']), L.ACT_RELU, L.view(ub['g']), B, st)       # in place when g is ub['g']
+            if not masked:
+                lib.act_bwd(L.view(g), L.view(ub['y']), L.ACT_RELU, L.view(ub['g']), B, st)       # in place when g is ub['g']
+            masked = False
             dst = p['ups'][ui - 1]['g'] if ui > 0 else p['gst'][0]
             lib.conv2d(L.view(ub['g']), self._up_bwd_weight(ui, up, bn), L.view(dst), B, 3, 2, 1, L.PAD_ZERO, False, None, L.ACT_NONE,
                        precision=prec, stream=st)
             g = dst
             if self.debug is not None:
                 self.debug[f'up{ui}_in'] = g.clone()
-        # g = d loss / d (state after the last block); walk the blocks backwards
-        gi = 0
-        for bi in range(len(self.blocks) - 1, -1, -1):
+        # g = d loss / d (state after the last block), kept in gst[0] and updated IN PLACE block by block (the identity path, ffc.py:288);
+        # gm = g * relu'(output of the block's second layer): an act_bwd launch for the last block, after that the second output of the
+        # fold that ends the reverse pass of the block downstream (M0 / M1: gm of the second layer, gm of the first layer)
+        if g is not p['gst'][0]:
+            raise LamaError('backward: the gradient of the block state must live in gst[0]')
+        m0, m1 = p['gst'][1], p['gst'][2]
+        nb = len(self.blocks)
+        lib.act_bwd(L.view(g), L.view(p['tapes'][nb - 1]['c2']['out']), self.blocks[nb - 1][2].lay._act, L.view(m0), B, st)
+        for bi in range(nb - 1, -1, -1):
             _, t1, t2 = self.blocks[bi]
             tp = p['tapes'][bi]
-            ga, gb = p['gst'][(gi + 1) % 3], p['gst'][(gi + 2) % 3]
-            t2.backward(g, ga, tp['c2'], p['sh'])              # d / d (conv1 output)
-            t1.backward(ga, gb, tp['c1'], p['sh'])             # d / d (block input) through the two layers
-            lib.add(L.view(gb), L.view(g), L.view(ga), B, st)  # + the identity path (ffc.py:288)
-            g, gi = ga, (gi + 1) % 3
+            if t1.lay._act != L.ACT_RELU or t2.lay._act != L.ACT_RELU:
+                raise LamaError('backward: resnet-block layers with a ReLU activation expected (ffc.py:253-254)')
+            t2.backward(m0, tp['c2'], p['sh'], None, m1, None, tp['c1']['out'])          # m1 = d / d (conv1 output) * relu'(conv1 output)
+            up_mask = p['tapes'][bi - 1]['c2']['out'] if bi > 0 else None
+            t1.backward(m1, tp['c1'], p['sh'], g, m0 if bi > 0 else None, g, up_mask)      # g += d / d (block input); m0 = g * relu'(...)
             if self.debug is not None:
                 self.debug[f'block{bi}_in'] = g.clone()
         return g

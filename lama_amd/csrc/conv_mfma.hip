@@ -498,7 +498,8 @@ extern "C" int32_t lama_winograd_supported(int32_t cout, int32_t cin, int32_t H,
 
 extern "C" int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes) {
     if (!a || !tensor_ok(a->x) || !tensor_ok(a->y) || !a->w_packed || a->batch <= 0) return LAMA_ERR_BAD_ARG;
-    if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad != 1 || a->pad_mode != LAMA_PAD_REFLECT || a->transposed) return LAMA_ERR_UNSUPPORTED;
+    if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad != 1 || (a->pad_mode != LAMA_PAD_REFLECT && a->pad_mode != LAMA_PAD_ZERO) || a->transposed)
+        return LAMA_ERR_UNSUPPORTED;
     if (a->x2.ptr || a->fuse1_w) return LAMA_ERR_UNSUPPORTED;
     if (a->x.dtype != LAMA_DT_F32 || a->y.dtype != LAMA_DT_F32 || (a->resid.ptr && a->resid.dtype != LAMA_DT_F32)) return LAMA_ERR_UNSUPPORTED;
     if (a->x.H != a->y.H || a->x.W != a->y.W || a->x.H < 2 || a->x.W < 2) return LAMA_ERR_BAD_ARG;

@@ -137,6 +137,271 @@ extern "C" int lama_reflect_pad_bwd(void* stream, const lama_tensor* gp, const l
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: the same adjoint with everything the reverse pass does to its result in the same pass over memory --
+//     s = fold(gp) [+ add1] [+ add2];      g = s (optional);      gm = s * act'(mask_y) (optional)
+// add1 = the 1x1 path into the same input (conv1 of the SpectralTransform), add2 = the identity path of the resnet block (ffc.py:288),
+// mask_y = the taped output of the layer UPSTREAM whose activation derivative the next reverse step starts with.  One launch instead of
+// fold + add_kernel + act_bwd_kernel (9.5 instead of 14.5 tensor passes per resnet block), V = 4 consecutive pixels of a row per thread
+// (16-byte loads / stores on everything but the padded plane, whose rows are W + 2 pad long).  g may be add2 itself (in place).
+// ------------------------------------------------------------------------------------------------
+struct FoldParams {
+    const float* gp; long long gp_bs;
+    const float* add1; long long add1_bs;
+    const float* add2; long long add2_bs;
+    const float* mask; long long mask_bs;
+    float* g; long long g_bs;
+    float* gm; long long gm_bs;
+    const float* ring;   // null: gp is the padded plane [B,C,H+2p,W+2p]; else gp is the INTERIOR [B,C,H,W] of it and ring [B][C][2(W+2)+2H] holds the one-pixel
+                         // frame around it (pad = 1): rows y = -1 and y = H for x = -1..W, then columns x = -1 and x = W for y = 0..H-1 (dgrad_ring_kernel)
+    int C, B, H, W, pad, act;
+};
+
+__device__ __forceinline__ float rf_act_deriv(int act, float y) {
+    if (act == LAMA_ACT_RELU) return y > 0.0f ? 1.0f : 0.0f;
+    if (act == LAMA_ACT_SIGMOID) return y * (1.0f - y);
+    if (act == LAMA_ACT_TANH) return 1.0f - y * y;
+    return 1.0f;
+}
+
+template <int V>
+__global__ __launch_bounds__(LAMA_NTHREADS) void reflect_pad_bwd_fused_kernel(FoldParams p) {
+    typedef float fv_t __attribute__((ext_vector_type(V)));
+    const int Hp = p.H + 2 * p.pad, Wp = p.W + 2 * p.pad, Wv = p.W / V;
+    const long long per = (long long)p.C * p.H * Wv, total = per * p.B;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / per);
+        const unsigned r = (unsigned)(i - (long long)b * per);          // C * H * W / V < 2^32 (checked by the host)
+        const int x0 = (int)(r % (unsigned)Wv) * V;
+        const unsigned r2 = r / (unsigned)Wv;
+        const int y = (int)(r2 % (unsigned)p.H);
+        const int c = (int)(r2 / (unsigned)p.H);
+        const long long off = ((long long)c * p.H + y) * p.W + x0;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.0f;
+        if (p.add1) {
+            const fv_t a = *reinterpret_cast<const fv_t*>(p.add1 + b * p.add1_bs + off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += a[e];
+        }
+        if (p.add2) {
+            const fv_t a = *reinterpret_cast<const fv_t*>(p.add2 + b * p.add2_bs + off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += a[e];
+        }
+        if (p.ring) {
+            const fv_t a = *reinterpret_cast<const fv_t*>(p.gp + b * p.gp_bs + off);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += a[e];
+            const bool ytop = y == 1, ybot = y == p.H - 2;
+            if (ytop || ybot || x0 <= 1 || x0 + V - 1 >= p.W - 2) {
+                const float* top = p.ring + ((long long)b * p.C + c) * (2 * (p.W + 2) + 2 * p.H);
+                const float *bot = top + p.W + 2, *left = bot + p.W + 2, *right = left + p.H;
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int x = x0 + e;
+                    float r = 0.0f;
+                    if (ytop) r += top[x + 1];
+                    if (ybot) r += bot[x + 1];
+                    if (x == 1) r += left[y] + (ytop ? top[0] : 0.0f) + (ybot ? bot[0] : 0.0f);
+                    if (x == p.W - 2) r += right[y] + (ytop ? top[p.W + 1] : 0.0f) + (ybot ? bot[p.W + 1] : 0.0f);
+                    acc[e] += r;
+                }
+            }
+        }
+        // padded rows that map to y: y + pad itself, pad - y (top mirror, 1 <= y <= pad), 2(H-1) - y + pad (bottom mirror)
+        int ys[3], ny = 0;
+        ys[ny++] = y + p.pad;
+        if (y >= 1 && y <= p.pad) ys[ny++] = p.pad - y;
+        if (y <= p.H - 2 && y >= p.H - 1 - p.pad) ys[ny++] = 2 * (p.H - 1) - y + p.pad;
+        if (p.ring) ny = 0;
+        const float* src = p.gp + b * p.gp_bs + (long long)c * Hp * Wp;
+        const bool xedge = x0 <= p.pad || x0 + V - 1 >= p.W - 1 - p.pad;      // some pixel of the group has a mirrored column
+        for (int a = 0; a < ny; ++a) {
+            const float* row = src + (long long)ys[a] * Wp;
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += row[x0 + e + p.pad];
+            if (xedge) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    const int x = x0 + e;
+                    if (x >= 1 && x <= p.pad) acc[e] += row[p.pad - x];
+                    if (x <= p.W - 2 && x >= p.W - 1 - p.pad) acc[e] += row[2 * (p.W - 1) - x + p.pad];
+                }
+            }
+        }
+        fv_t s;
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] = acc[e];
+        if (p.g) *reinterpret_cast<fv_t*>(p.g + b * p.g_bs + off) = s;
+        if (p.gm) {
+            if (p.mask) {
+                const fv_t m = *reinterpret_cast<const fv_t*>(p.mask + b * p.mask_bs + off);
+#pragma unroll
+                for (int e = 0; e < V; ++e) s[e] *= rf_act_deriv(p.act, m[e]);
+            }
+            *reinterpret_cast<fv_t*>(p.gm + b * p.gm_bs + off) = s;
+        }
+    }
+}
+
+extern "C" int lama_reflect_pad_bwd_fused(void* stream, const lama_tensor* gp, const lama_tensor* add1, const lama_tensor* add2, int32_t pad,
+                                          const lama_tensor* mask_y, int32_t act, const lama_tensor* g, const lama_tensor* gm, int32_t batch,
+                                          const float* ring) {
+    const lama_tensor* out = (g && g->ptr) ? g : gm;
+    if (!rf_ok(gp) || !rf_ok(out) || batch <= 0 || pad < 0) return LAMA_ERR_BAD_ARG;
+    const int gpad = ring ? 0 : pad;      // with a ring, gp is the interior of the padded plane
+    if (ring && pad != 1) return LAMA_ERR_BAD_ARG;
+    if (gp->C != out->C || gp->H != out->H + 2 * gpad || gp->W != out->W + 2 * gpad || pad >= out->H || pad >= out->W) return LAMA_ERR_BAD_ARG;
+    if ((long long)out->C * out->H * out->W >= (1ll << 32)) return LAMA_ERR_UNSUPPORTED;
+    FoldParams p;
+    memset(&p, 0, sizeof(p));
+    uintptr_t al = 0;
+    long long sal = 0;
+    auto opt = [&](const lama_tensor* t, const float*& ptr, long long& bs) -> bool {
+        if (!t || !t->ptr) return true;
+        if (!rf_ok(t) || !rf_same(t, out)) return false;
+        ptr = (const float*)t->ptr; bs = t->batch_stride;
+        al |= (uintptr_t)t->ptr; sal |= t->batch_stride;
+        return true;
+    };
+    const float *pg = nullptr, *pgm = nullptr;
+    if (!opt(add1, p.add1, p.add1_bs) || !opt(add2, p.add2, p.add2_bs) || !opt(mask_y, p.mask, p.mask_bs) || !opt(g, pg, p.g_bs) ||
+        !opt(gm, pgm, p.gm_bs))
+        return LAMA_ERR_BAD_ARG;
+    p.g = const_cast<float*>(pg); p.gm = const_cast<float*>(pgm);
+    if (p.gm && p.gm == p.g) return LAMA_ERR_BAD_ARG;
+    p.gp = (const float*)gp->ptr; p.gp_bs = gp->batch_stride;
+    p.ring = ring;
+    if (ring) { al |= (uintptr_t)gp->ptr; sal |= gp->batch_stride; }
+    p.C = out->C; p.B = batch; p.H = out->H; p.W = out->W; p.pad = pad; p.act = p.mask ? act : LAMA_ACT_NONE;
+    const long long n = (long long)out->C * out->H * out->W * batch;
+    if (out->W % 4 == 0 && (al & 15) == 0 && sal % 4 == 0) {
+        hipLaunchKernelGGL(reflect_pad_bwd_fused_kernel<4>, dim3(rf_grid(n / 4)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    } else {
+        hipLaunchKernelGGL(reflect_pad_bwd_fused_kernel<1>, dim3(rf_grid(n)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    }
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the one-pixel FRAME of a 3x3 dgrad.  The data gradient of a reflect-padded 3x3 conv is fold(gp), gp = the zero-padded correlation of
+// the output gradient with the flipped weights evaluated on the PADDED plane (H+2) x (W+2).  Its interior H x W is an ordinary zero-pad-1 conv
+// (which the Winograd kernel computes with 16/36 of the products and on exactly H W / 128 tiles -- the padded plane of a 256 x 256 state is
+// 585 tiles of 128 pixels on 512 workgroup slots); what the fold needs beyond it is the frame: rows y = -1, H and columns x = -1, W, where
+// only ONE row (column) of the 3x3 taps reaches the plane:
+//     ring[e][t][o] = sum_c sum_k wr[e][c][k][o] * line_e[c][t + k - 1]
+// e = top / bottom / left / right, line_e = row 0 / row H-1 / column 0 / column W-1 of the gradient (zero outside), t = -1..W (rows) or 0..H-1
+// (columns), wr[top] = w'[o][c][2][k], wr[bottom] = w'[o][c][0][k], wr[left] = w'[o][c][k][2], wr[right] = w'[o][c][k][0]  (w' = the flipped,
+// transposed weights of the dgrad conv).  0.4 % of the conv's products at 256 x 256: exact fp32 on the vector ALUs, the weights are read
+// coalesced along o.
+// ------------------------------------------------------------------------------------------------
+struct RingParams {
+    const float* g; long long g_bs;
+    const float* wr;
+    float* ring;
+    int C, H, W, M, B;
+};
+
+// Workgroup = PP consecutive frame positions x 128 output channels x 8 channel groups (1024 threads): the line values of ALL input channels
+// for these positions go to LDS in one round of loads (the launch is a chain of memory latencies, not of FMAs: the first version, one thread
+// per (o, 8 positions) walking all 512 channels, took 228 us), every thread then walks C / 8 channels with its weights eight channels ahead,
+// and the eight partial sums meet in LDS in a fixed order.
+template <int PP>
+__global__ __launch_bounds__(1024) void dgrad_ring_kernel(RingParams p) {
+    float* const lin = reinterpret_cast<float*>(lama_smem);            // [C][PP + 2]
+    const int lin_n = (p.C * (PP + 2) + 5119) / 5120 * 5120;           // whole staging rounds of 5 values x 1024 threads
+    float* const red = lin + lin_n;                                    // [8][PP][128]
+    const int nTB = (p.W + 2 + PP - 1) / PP, nLR = (p.H + PP - 1) / PP;
+    int seg = blockIdx.x, e;
+    if (seg < 2 * nTB) { e = seg / nTB; seg -= e * nTB; }
+    else { seg -= 2 * nTB; e = 2 + seg / nLR; seg -= (e - 2) * nLR; }
+    const int tid = threadIdx.x, cg = LAMA_WAVE_UNIFORM(tid >> 7), ol = tid & 127;
+    const int o = blockIdx.y * 128 + ol, b = blockIdx.z;
+    const bool rows = e < 2;
+    const int elen = rows ? p.W + 2 : p.H, llen = rows ? p.W : p.H, stride = rows ? 1 : p.W;
+    const int base = e == 0 ? 0 : (e == 1 ? (p.H - 1) * p.W : (e == 2 ? 0 : p.W - 1));
+    const int j0 = seg * PP;                               // first frame position of this workgroup (index along the edge)
+    const int i0 = j0 + (rows ? -1 : 0) - 1;               // line index of tap 0 of that position
+    const long long HW = (long long)p.H * p.W;
+    const lama_buf_t gres = LAMA_BUF_RSRC(p.g + (long long)b * p.g_bs, (long long)p.C * HW * 4);
+    // all loads of a round in flight before the first LDS write (the compiler's own order was load, wait, write, five times over)
+    for (int base_i = 0; base_i < p.C * (PP + 2); base_i += 5 * 1024) {
+        float v[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int idx = base_i + u * 1024 + tid;
+            int c = idx / (PP + 2);
+            const int jj = idx - c * (PP + 2), i = i0 + jj;
+            // raw buffer loads: a position outside the line (or past the last channel) gets an offset beyond the buffer's range and reads 0 --
+            // no branch around the load (hipcc sinks a plain load into the branch of its select, and each then ends in a wait of its own)
+            const unsigned off = (c < p.C && i >= 0 && i < llen) ? (unsigned)((c * (int)HW + base + i * stride) * 4) : 0xfffffff0u;
+            v[u] = __builtin_bit_cast(float, LAMA_BUF_LOAD_B32(gres, off, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) lin[base_i + u * 1024 + tid] = v[u];       // (lin is padded to whole rounds: no condition, no branch)
+    }
+    __syncthreads();
+    float acc[PP];
+#pragma unroll
+    for (int q = 0; q < PP; ++q) acc[q] = 0.0f;
+    const int cper = p.C >> 3;                             // a multiple of 8 (host)
+    const float* wb = p.wr + ((long long)e * p.C + cg * cper) * 3 * p.M + o;
+    const float* lb = lin + cg * cper * (PP + 2);
+    // weights eight channels ahead in registers: one L2 latency per eight channels, under the FMAs of the eight before
+    float wc[24], wn[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) wc[k] = wb[(long long)k * p.M];
+#pragma unroll 1
+    for (int c0 = 0; c0 < cper; c0 += 8) {
+        const int cn = c0 + 8 < cper ? c0 + 8 : c0;                      // (the last round re-reads its own weights: no branch around the loads)
+#pragma unroll
+        for (int k = 0; k < 24; ++k) wn[k] = wb[(long long)(cn * 3 + k) * p.M];
+        __builtin_amdgcn_sched_barrier(0);                                // the requests first, then this round's FMAs
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float* in = lb + (c0 + u) * (PP + 2);
+#pragma unroll
+            for (int q = 0; q < PP; ++q) acc[q] = fmaf(wc[3 * u], in[q], fmaf(wc[3 * u + 1], in[q + 1], fmaf(wc[3 * u + 2], in[q + 2], acc[q])));
+        }
+#pragma unroll
+        for (int k = 0; k < 24; ++k) wc[k] = wn[k];
+    }
+#pragma unroll
+    for (int q = 0; q < PP; ++q) red[(cg * PP + q) * 128 + ol] = acc[q];
+    __syncthreads();
+    {
+        const int q = tid >> 7;                            // 1024 threads = PP (= 8) positions x 128 channels
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += red[(k * PP + q) * 128 + ol];
+        const int RL = 2 * (p.W + 2) + 2 * p.H;
+        const int eoff = e == 0 ? 0 : (e == 1 ? p.W + 2 : (e == 2 ? 2 * (p.W + 2) : 2 * (p.W + 2) + p.H));
+        if (j0 + q < elen) p.ring[((long long)b * p.M + o) * RL + eoff + j0 + q] = sum;
+    }
+}
+
+extern "C" size_t lama_dgrad_ring_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W) {
+    if (batch <= 0 || cout <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)batch * cout * (2 * (W + 2) + 2 * H) * sizeof(float);
+}
+
+extern "C" int lama_dgrad_ring_fwd(void* stream, const lama_tensor* g, const float* w_ring, int32_t cout, float* ring, int32_t batch) {
+    if (!rf_ok(g) || !w_ring || !ring || batch <= 0 || cout <= 0) return LAMA_ERR_BAD_ARG;
+    constexpr int PP = 8;                                   // = 1024 threads / 128 output channels (the reduction's thread map)
+    const size_t shmem = (((size_t)g->C * (PP + 2) + 5119) / 5120 * 5120 + 8 * PP * 128) * sizeof(float);
+    if (cout % 128 != 0 || g->C % 64 != 0 || g->H < 2 || g->W < 2 || batch > 65535 || shmem > 96 * 1024 || (long long)g->C * g->H * g->W * 4 >= (1ll << 31))
+        return LAMA_ERR_UNSUPPORTED;
+    RingParams p = {(const float*)g->ptr, g->batch_stride, w_ring, ring, g->C, g->H, g->W, cout, batch};
+    const int nTB = (g->W + 2 + PP - 1) / PP, nLR = (g->H + PP - 1) / PP;
+    hipLaunchKernelGGL(dgrad_ring_kernel<PP>, dim3(2 * nTB + 2 * nLR, cout / 128, batch), dim3(1024), shmem, (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // kornia.filters.gaussian_blur2d(x, (5,5), (1,1)), border_type='reflect' (refinement.py:24,52), on the top-left crop
 // [0:y.H, 0:y.W] of x (refinement.py:149 blurs pred[:, :, :orig_h, :orig_w]); and its adjoint (zeros outside the crop).
 // ------------------------------------------------------------------------------------------------

@@ -515,3 +515,10 @@ def test_winograd_conv3x3_emulated(case, prec):
     assert float((y - yd).abs().max()) < 2 * tol['atol']
     with pytest.raises(L.LamaError):                                         # workspace too small
         lib.winograd_conv3x3(L.view(xbuf, 1, cin), wp, L.view(ybuf, 2, cout), B, ws[:16], bias, case['act'], None, precision=prec)
+    if case['cin'] <= 64 and cout == 128:
+        # round 4: zero padding (the dgrad convs of the reverse pass): rows / columns outside the plane read as zeros, first / last band and column
+        refz = _conv_ref(x, w, 1, 1, False, False, bias, case['act'], resid, scale=scale)
+        lib.winograd_conv3x3(L.view(xbuf, 1, cin), wp, L.view(ybuf, 2, cout), B, ws, bias, case['act'], None if resid is None else L.view(resid),
+                             precision=prec, range_flag=flag, pad_mode=L.PAD_ZERO)
+        assert torch.allclose(ybuf[:, 2:2 + cout], refz, **tol), float((ybuf[:, 2:2 + cout] - refz).abs().max())
+        assert float((refz - ref).abs().max()) > 0.1

@@ -45,6 +45,65 @@ def test_reflect_pad_adjoint(case):
     assert torch.allclose(g, x.grad + add, atol=1e-6)
 
 
+@pytest.mark.parametrize('case', [(1, 8, 8), (1, 6, 12), (3, 12, 5), (2, 4, 4), (3, 8, 16)])
+def test_reflect_pad_adjoint_fused(case):
+    """lama_reflect_pad_bwd_fused (v108): fold + the 1x1 path + the identity path (in place) + the activation derivative of the layer upstream,
+    against the separate launches it replaces; W % 4 == 0 takes the 16-byte path, the rest the scalar one; views with a channel offset."""
+    lib = emu_lib()
+    pad, H, W = case
+    gp = torch.randn(2, 5, H + 2 * pad, W + 2 * pad, generator=_g(4))
+    add1, add2 = torch.randn(2, 5, H, W, generator=_g(5)), torch.randn(2, 7, H, W, generator=_g(6))
+    y = torch.randn(2, 7, H, W, generator=_g(7))
+    fold = torch.zeros(2, 5, H, W)
+    lib.reflect_pad_bwd(L.view(gp), None, pad, L.view(fold), 2)
+    for act, d in ((L.ACT_RELU, (y > 0).float()), (L.ACT_TANH, 1 - y * y)):
+        s = fold + add1 + add2[:, 2:7]
+        g, gm = torch.full((2, 7, H, W), 9.0), torch.full((2, 7, H, W), 9.0)
+        lib.reflect_pad_bwd_fused(L.view(gp), L.view(add1), L.view(add2, 2, 5), pad, L.view(y, 2, 5), act, L.view(g, 2, 5), L.view(gm, 2, 5), 2)
+        assert torch.equal(g[:, 2:7], s) or torch.allclose(g[:, 2:7], s, atol=1e-6)
+        assert torch.allclose(gm[:, 2:7], s * d[:, 2:7], atol=1e-6) and float(g[:, :2].min()) == 9.0 and float(gm[:, :2].min()) == 9.0
+    # in place over the identity operand, no mask, one output at a time
+    acc = add2.clone()
+    lib.reflect_pad_bwd_fused(L.view(gp), None, L.view(acc, 2, 5), pad, None, L.ACT_NONE, L.view(acc, 2, 5), None, 2)
+    assert torch.allclose(acc[:, 2:7], fold + add2[:, 2:7], atol=1e-6) and torch.equal(acc[:, :2], add2[:, :2])
+    gm = torch.zeros(2, 5, H, W)
+    lib.reflect_pad_bwd_fused(L.view(gp), None, None, pad, L.view(y, 0, 5), L.ACT_RELU, None, L.view(gm), 2)
+    assert torch.allclose(gm, fold * (y[:, :5] > 0).float(), atol=1e-6)
+    with pytest.raises(L.LamaError):
+        lib.reflect_pad_bwd_fused(L.view(gp), None, None, pad, None, L.ACT_NONE, None, None, 2)
+
+
+@pytest.mark.parametrize('case', [(8, 8), (5, 12), (20, 7), (3, 3), (2, 4)])
+def test_dgrad_ring_and_fold_from_interior(case):
+    """Round 4 (v108): the data gradient of a reflect-padded 3x3 conv without its padded plane -- lama_dgrad_ring_fwd computes the one-pixel
+    frame of the zero-padded correlation (exact fp32), lama_reflect_pad_bwd_fused(ring=...) folds it onto the interior (a zero-pad-1 conv).
+    Reference: autograd through F.pad(mode='reflect') + conv2d."""
+    lib = emu_lib()
+    H, W = case
+    cin, cout = 64, 128                                      # dgrad: 64 gradient channels in (8 channel groups x 8 channels ahead), 128 data channels out
+    wf = torch.randn(cin, cout, 3, 3, generator=_g(8)) * 0.1   # forward conv weight [out = 64, in = 128]
+    x = torch.randn(2, cout, H, W, generator=_g(9), requires_grad=True)
+    gy = torch.randn(2, cin, H, W, generator=_g(10))
+    F.conv2d(F.pad(x, (1,) * 4, mode='reflect'), wf).backward(gy)
+    wd = wf.permute(1, 0, 2, 3).flip(2, 3).contiguous()      # w' [128, 64, 3, 3]
+    gp = F.conv2d(F.pad(gy, (2,) * 4), wd)                   # the padded plane [2, 128, H + 2, W + 2]
+    ring = torch.full((lib.dgrad_ring_bytes(2, cout, H, W) // 4 + 3,), 5.0)
+    lib.dgrad_ring(L.view(gy), lib.dgrad_ring_weight(wd), cout, ring, 2)
+    r = ring[:-3].view(2, cout, -1)
+    assert float(ring[-3:].min()) == 5.0
+    assert torch.allclose(r[:, :, :W + 2], gp[:, :, 0], atol=1e-5) and torch.allclose(r[:, :, W + 2:2 * W + 4], gp[:, :, -1], atol=1e-5)
+    assert torch.allclose(r[:, :, 2 * W + 4:2 * W + 4 + H], gp[:, :, 1:-1, 0], atol=1e-5)
+    assert torch.allclose(r[:, :, 2 * W + 4 + H:], gp[:, :, 1:-1, -1], atol=1e-5)
+    interior = gp[:, :, 1:-1, 1:-1].contiguous()
+    ident, y = torch.randn(2, cout, H, W, generator=_g(11)), torch.randn(2, cout, H, W, generator=_g(12))
+    g, gm = torch.zeros(2, cout, H, W), torch.zeros(2, cout, H, W)
+    lib.reflect_pad_bwd_fused(L.view(interior), None, L.view(ident), 1, L.view(y), L.ACT_RELU, L.view(g), L.view(gm), 2, ring=ring)
+    assert torch.allclose(g, x.grad + ident, atol=2e-5), float((g - x.grad - ident).abs().max())
+    assert torch.allclose(gm, (x.grad + ident) * (y > 0).float(), atol=2e-5)
+    with pytest.raises(L.LamaError):
+        lib.reflect_pad_bwd_fused(L.view(gp), None, None, 1, None, L.ACT_NONE, L.view(g), None, 2, ring=ring)     # gp must be the interior
+
+
 @pytest.mark.parametrize('shape', [(16, 24, 16, 24), (16, 24, 13, 21), (9, 8, 5, 6)])
 def test_gauss5_crop_fwd_and_adjoint(shape):
     lib = emu_lib()

@@ -212,3 +212,27 @@ def test_first_iteration_gradient_18_blocks(biglama_module, golden_dir, precs):
     assert loss_rel.max() < 1e-4, loss_rel
     assert rel_g < 2.0 * float(g['self_rel'][1]), (rel_g, g['self_rel'])
     assert corr > 0.999 and abs(norm_ratio - 1.0) < 5e-3, (corr, norm_ratio)
+
+
+@pytest.mark.parametrize('case', [(1, 64, 64), (1, 30, 50), (3, 128, 256)])
+def test_reflect_pad_adjoint_fused_matches_separate_launches(case):
+    """lama_reflect_pad_bwd_fused (v108) against fold + add + act_bwd as separate launches, on channel views of the 512-channel state
+    (same terms, another order of the additions)."""
+    lib = F._DEFAULT_EXEC.lib
+    pad, H, W = case
+    gen = torch.Generator().manual_seed(11)
+    gp = torch.randn(2, 384, H + 2 * pad, W + 2 * pad, generator=gen).to(DEV)
+    add1 = torch.randn(2, 384, H, W, generator=gen).to(DEV)
+    ident, y = torch.randn(2, 512, H, W, generator=gen).to(DEV), torch.randn(2, 512, H, W, generator=gen).to(DEV)
+    fold = torch.empty(2, 384, H, W, device=DEV)
+    lib.reflect_pad_bwd(L.view(gp), L.view(add1), pad, L.view(fold), 2)
+    s = torch.empty_like(fold)
+    lib.add(L.view(fold), L.view(ident, 128, 384), L.view(s), 2)
+    sm = torch.empty_like(s)
+    lib.act_bwd(L.view(s), L.view(y, 128, 384), L.ACT_RELU, L.view(sm), 2)
+    g, gm = ident.clone(), torch.zeros(2, 512, H, W, device=DEV)
+    lib.reflect_pad_bwd_fused(L.view(gp), L.view(add1), L.view(g, 128, 384), pad, L.view(y, 128, 384), L.ACT_RELU, L.view(g, 128, 384),
+                              L.view(gm, 128, 384), 2)
+    torch.cuda.synchronize()
+    assert torch.allclose(g[:, 128:], s, atol=1e-5, rtol=0) and torch.allclose(gm[:, 128:], sm, atol=1e-5, rtol=0)      # (the order of the additions differs)
+    assert torch.equal(g[:, :128], ident[:, :128]) and float(gm[:, :128].abs().max()) == 0.0

@@ -17,6 +17,7 @@
 #   ab:<ENV>=<v1>,<v2>[,...]   same-box A/B of an environment switch of the PROFILING library, two rounds   -> ab_<ENV>.txt
 #   ablib:<path/base.so>       same-box A/B of another build of the library against the in-tree one (LAMA_HIP_LIB)
 #   py:<script> [args]         python <script> args  (quote the step)                      -> py_<script>.log
+#   statspy:<script> [args]    rocprofv3 kernel stats of python <script> args              -> kernel_stats_<script>.csv
 TAG=${1:?usage: session.sh <tag> <step>...}; shift
 O=gpurun_out/$TAG
 mkdir -p $O
@@ -47,6 +48,10 @@ for STEP in "$@"; do
     stats)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
             for db in $(find $O/prof -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats.csv; python tools/timeline.py $db $O/timeline.txt 4; done
             rm -rf $O/prof; head -16 $O/kernel_stats.csv | cut -c1-170 | tee -a $O/summary.txt ;;
+    statspy) set -- $ARG; N=$(basename $1 .py)
+            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof_$N -o run -- python $ROOT/$1 ${@:2} > $ROOT/$O/prof_$N.log 2>&1)
+            for db in $(find $O/prof_$N -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats_$N.csv; done
+            rm -rf $O/prof_$N; tail -3 $O/prof_$N.log | tee -a $O/summary.txt; head -40 $O/kernel_stats_$N.csv | cut -c1-200 | tee -a $O/summary.txt ;;
     pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
     pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
               (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
