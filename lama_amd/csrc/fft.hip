@@ -810,6 +810,7 @@ __device__ __forceinline__ void ipn_pass(float2* buf, const float2* tw, int Ns, 
             for (int r = 1; r < R; ++r) v[it][r] = cmul(v[it][r], tw[r * k * (N / (Ns * R))]);
         }
         if constexpr (R == 8) dft8<INV>(v[it]);
+        else if constexpr (R == 4) dft4<INV>(v[it][0], v[it][1], v[it][2], v[it][3]);
         else dft2<INV>(v[it][0], v[it][1]);
     }
     __syncthreads();
@@ -1262,7 +1263,7 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void dft_rows_inv_kernel(FftParams p
 // the same row-pair packing as the one-pass kernels; the DC / Nyquist columns are simply transformed like every other
 // column (wf = w/2 + 1 column FFTs instead of w/2).
 // ------------------------------------------------------------------------------------------------
-#define FFT2P_PAIRS 8   // row pairs per workgroup (pass R)
+#define FFT2P_PAIRS 8  // row pairs per workgroup (pass R)
 #define FFT2P_COLS 8    // columns per workgroup (pass C)
 
 // forward rows: ws[plane][y][k] = half spectrum of row y (unscaled)
@@ -1389,6 +1390,225 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fft2p_rows_inv_kernel(FftParams
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: the two passes for 256 x 256 planes (the bottleneck planes of 2048 x 2048 inputs: BASELINE configs[4]) with compile-time sizes.
+// The generic kernels above spend their time on run-time index arithmetic and 4-byte accesses (61 / 60 / 33 / 43 us per pass on 192 planes,
+// 1.6 - 3 TB/s; 16 instead of 8 rows / columns per workgroup changes nothing: profiles/r04_fft256.txt).  Here: the one-buffer in-place passes of
+// the 128 x 128 kernel (radix 8, 8, 4), 16-byte global accesses on the activation and the workspace side, and the workspace holds 128
+// columns per row -- column 0 packs the DC and the Nyquist column (both real after the row pass; Hermitian-symmetrised before the inverse
+// column pass, as in irfft2_ipn_kernel), so a row is 1024 bytes and a group of 16 columns is one aligned 128-byte segment per row.
+//   rows:    workgroup = 8 row pairs of a plane (8 complex FFTs, 16.4 KB of LDS),   grid = planes x 16
+//   columns: workgroup = 16 columns x 256 rows (16 FFTs, 34.8 KB),                   grid = planes x 8
+// ------------------------------------------------------------------------------------------------
+#define FQ_N 256
+#define FQ_PAIRS 8
+#ifndef FQ_CW
+#define FQ_CW 32      // 16: 34.8 KB of LDS, four workgroups per CU, 64-byte segments of the spectrum planes; 32: 67.6 KB, two per CU, 128-byte segments
+#endif
+#define FQ_CP (FQ_CW + 1)
+
+template <bool INV>
+__device__ __forceinline__ void fq_fft_rows(float2* buf, const float2* tw) {      // FQ_PAIRS FFTs, element stride 1, FFT stride FQ_N + 1
+    ipn_pass<8, FQ_N, FQ_PAIRS, INV>(buf, tw, 1, 1, FQ_N + 1);
+    ipn_pass<8, FQ_N, FQ_PAIRS, INV>(buf, tw, 8, 1, FQ_N + 1);
+    ipn_pass<4, FQ_N, FQ_PAIRS, INV>(buf, tw, 64, 1, FQ_N + 1);
+}
+template <bool INV>
+__device__ __forceinline__ void fq_fft_cols(float2* buf, const float2* tw) {      // FQ_CW FFTs, element stride FQ_CP, FFT stride 1
+    ipn_pass<8, FQ_N, FQ_CW, INV>(buf, tw, 1, FQ_CP, 1);
+    ipn_pass<8, FQ_N, FQ_CW, INV>(buf, tw, 8, FQ_CP, 1);
+    ipn_pass<4, FQ_N, FQ_CW, INV>(buf, tw, 64, FQ_CP, 1);
+}
+
+// forward rows: ws[plane][y][k], k = 0 .. 127 (k = 0: (DC, Nyquist) of row y), unscaled
+__global__ __launch_bounds__(LAMA_NTHREADS) void fq_rows_fwd_kernel(FftParams p, float2* ws) {
+    constexpr int N = FQ_N, wh = N / 2, RSW = N + 1, NP = FQ_PAIRS;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tw + N;
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x / (wh / NP), f0 = (blockIdx.x % (wh / NP)) * NP;
+    const int b = plane / p.C, c = plane - b * p.C;
+    const float* src = (const float*)p.x + (long long)b * p.x_bstride + (long long)c * N * N + (long long)(2 * f0) * N;
+    float4 ra[2], rb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {          // NP pairs x 64 float4 columns = 512 items
+        const int item = tid + it * LAMA_NTHREADS, f = item >> 6, q = item & 63;
+        ra[it] = *reinterpret_cast<const float4*>(src + (2 * f) * N + q * 4);
+        rb[it] = *reinterpret_cast<const float4*>(src + (2 * f + 1) * N + q * 4);
+    }
+    fft_init_twiddles<false>(tw, N);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * LAMA_NTHREADS, f = item >> 6, q = item & 63;
+        float2* d = P + f * RSW + q * 4;
+        d[0] = make_float2(ra[it].x, rb[it].x);
+        d[1] = make_float2(ra[it].y, rb[it].y);
+        d[2] = make_float2(ra[it].z, rb[it].z);
+        d[3] = make_float2(ra[it].w, rb[it].w);
+    }
+    __syncthreads();
+    fq_fft_rows<false>(P, tw);
+    float2* out = ws + ((long long)plane * N + 2 * f0) * wh;
+#pragma unroll
+    for (int it = 0; it < NP * wh / LAMA_NTHREADS; ++it) {       // (pair, k) items, k fastest: 8-byte stores, 512 contiguous bytes per wave
+        const int item = tid + it * LAMA_NTHREADS, f = item >> 7, k = item & (wh - 1);
+        const float2* z = P + f * RSW;
+        float2 za, zb;
+        if (k == 0) {
+            const float2 z0 = z[0], zn = z[wh];
+            za = make_float2(z0.x, zn.x);
+            zb = make_float2(z0.y, zn.y);
+        } else {
+            const float2 zk = z[k], zm = z[N - k];
+            za = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+            zb = make_float2(0.5f * (zk.y + zm.y), 0.5f * (zm.x - zk.x));
+        }
+        out[(2 * f) * wh + k] = za;
+        out[(2 * f + 1) * wh + k] = zb;
+    }
+}
+
+// columns.  forward: spec[u][k] = scale * FFT_h(ws[.][k]) (column 0 of ws untangled into the DC and the Nyquist column); inverse:
+// ws[y][k] = IFFT_h(spec[.][k]), unscaled, columns 0 and N/2 of spec Hermitian-symmetrised along h and packed into column 0
+template <bool INV>
+__global__ __launch_bounds__(LAMA_NTHREADS) void fq_cols_kernel(FftParams p, float2* ws) {
+    constexpr int N = FQ_N, wh = N / 2, wf = N / 2 + 1, CW = FQ_CW, CP = FQ_CP;
+    constexpr int QW = CW / 2, QL = CW == 32 ? 4 : 3, CL = QL + 1;      // float4 (two columns) per row of the group, log2 of it, log2(CW)
+    static_assert(CW == 16 || CW == 32, "column group");
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tw + N;
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x / (wh / CW), k0 = (blockIdx.x % (wh / CW)) * CW;
+    const int b = plane / p.C, c = plane - b * p.C;
+    const long long per_plane = (long long)N * wf;
+    float* sre = (float*)p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
+    float* sim = sre + per_plane;
+    float2* wp = ws + (long long)plane * N * wh;
+    if constexpr (!INV) {
+        // 256 rows x QW float4 (two columns each): one aligned 128 / 256-byte segment per row
+        float4 v[QW];
+#pragma unroll
+        for (int it = 0; it < QW; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, y = item >> QL, q = item & (QW - 1);
+            v[it] = *reinterpret_cast<const float4*>(wp + (long long)y * wh + k0 + 2 * q);
+        }
+        fft_init_twiddles<false>(tw, N);
+#pragma unroll
+        for (int it = 0; it < QW; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, y = item >> QL, q = item & (QW - 1);
+            P[y * CP + 2 * q] = make_float2(v[it].x, v[it].y);
+            P[y * CP + 2 * q + 1] = make_float2(v[it].z, v[it].w);
+        }
+        __syncthreads();
+        fq_fft_cols<false>(P, tw);
+        // rows u, 16 columns each: 64-byte segments of the Re and of the Im plane (the layout lama_tensor fixes)
+#pragma unroll
+        for (int it = 0; it < N * CW / LAMA_NTHREADS; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, u = item >> CL, kk = item & (CW - 1);
+            float2 v2 = P[u * CP + kk];
+            if (k0 + kk == 0) {       // the packed column: DC = Hermitian part, Nyquist = anti-Hermitian part / i
+                const float2 cc = v2, cm = P[((N - u) & (N - 1)) * CP];
+                v2 = make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y));
+                const float2 ny = make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
+                sre[(long long)u * wf + wh] = ny.x * p.scale;
+                sim[(long long)u * wf + wh] = ny.y * p.scale;
+            }
+            sre[(long long)u * wf + k0 + kk] = v2.x * p.scale;
+            sim[(long long)u * wf + k0 + kk] = v2.y * p.scale;
+        }
+    } else {
+        fft_init_twiddles<true>(tw, N);
+#pragma unroll
+        for (int it = 0; it < N * CW / LAMA_NTHREADS; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, u = item >> CL, kk = item & (CW - 1);
+            const long long o = (long long)u * wf + k0 + kk;
+            P[u * CP + kk] = make_float2(sre[o], sim[o]);
+        }
+        float2 g = make_float2(0.f, 0.f);
+        if (k0 == 0) {                // workgroup-uniform
+            __syncthreads();
+            const int u = tid, um = (N - u) & (N - 1);                                  // 256 threads = 256 rows
+            const float2 d = P[u * CP], dm = P[um * CP];
+            const float2 e = make_float2(sre[(long long)u * wf + wh], sim[(long long)u * wf + wh]);
+            const float2 em = make_float2(sre[(long long)um * wf + wh], sim[(long long)um * wf + wh]);
+            const float2 dh = make_float2(0.5f * (d.x + dm.x), 0.5f * (d.y - dm.y));
+            const float2 eh = make_float2(0.5f * (e.x + em.x), 0.5f * (e.y - em.y));
+            g = make_float2(dh.x - eh.y, dh.y + eh.x);
+            __syncthreads();
+            P[u * CP] = g;
+        }
+        __syncthreads();
+        fq_fft_cols<true>(P, tw);
+#pragma unroll
+        for (int it = 0; it < QW; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, y = item >> QL, q = item & (QW - 1);
+            const float2 a = P[y * CP + 2 * q], bb = P[y * CP + 2 * q + 1];
+            *reinterpret_cast<float4*>(wp + (long long)y * wh + k0 + 2 * q) = make_float4(a.x, a.y, bb.x, bb.y);
+        }
+    }
+}
+
+// inverse rows: c2r of the ws rows, two rows per complex FFT, scale, fused residual add
+__global__ __launch_bounds__(LAMA_NTHREADS) void fq_rows_inv_kernel(FftParams p, const float2* ws) {
+    constexpr int N = FQ_N, wh = N / 2, RSW = N + 1, NP = FQ_PAIRS;
+    float2* tw = reinterpret_cast<float2*>(lama_smem);
+    float2* P = tw + N;
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.x / (wh / NP), f0 = (blockIdx.x % (wh / NP)) * NP;
+    const int b = plane / p.C, c = plane - b * p.C;
+    const float2* in = ws + ((long long)plane * N + 2 * f0) * wh;
+    float2 za[NP * wh / LAMA_NTHREADS], zb[NP * wh / LAMA_NTHREADS];
+#pragma unroll
+    for (int it = 0; it < NP * wh / LAMA_NTHREADS; ++it) {
+        const int item = tid + it * LAMA_NTHREADS, f = item >> 7, k = item & (wh - 1);
+        za[it] = in[(2 * f) * wh + k];
+        zb[it] = in[(2 * f + 1) * wh + k];
+    }
+    // the residual rows, requested behind the spectrum (used at the store)
+    const long long obase = (long long)c * N * N + (long long)(2 * f0) * N;
+    const float* rs = p.x ? (const float*)p.x + (long long)b * p.x_bstride + obase : nullptr;
+    float4 xa[2], xb[2];
+    if (rs) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, f = item >> 6, q = item & 63;
+            xa[it] = *reinterpret_cast<const float4*>(rs + (2 * f) * N + q * 4);
+            xb[it] = *reinterpret_cast<const float4*>(rs + (2 * f + 1) * N + q * 4);
+        }
+    }
+    fft_init_twiddles<true>(tw, N);
+#pragma unroll
+    for (int it = 0; it < NP * wh / LAMA_NTHREADS; ++it) {
+        const int item = tid + it * LAMA_NTHREADS, f = item >> 7, k = item & (wh - 1);
+        float2* z = P + f * RSW;
+        const float2 a = za[it], bb = zb[it];
+        if (k == 0) {
+            z[0] = make_float2(a.x, bb.x);
+            z[wh] = make_float2(a.y, bb.y);
+        } else {
+            z[k] = make_float2(a.x - bb.y, a.y + bb.x);
+            z[N - k] = make_float2(a.x + bb.y, bb.x - a.y);
+        }
+    }
+    __syncthreads();
+    fq_fft_rows<true>(P, tw);
+    float* dst = (float*)p.y + (long long)b * p.y_bstride + obase;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * LAMA_NTHREADS, f = item >> 6, q = item & 63;
+        const float2* s = P + f * RSW + q * 4;
+        const float2 v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+        float4 oa = make_float4(v0.x * p.scale, v1.x * p.scale, v2.x * p.scale, v3.x * p.scale);
+        float4 ob = make_float4(v0.y * p.scale, v1.y * p.scale, v2.y * p.scale, v3.y * p.scale);
+        if (rs) {
+            oa.x += xa[it].x; oa.y += xa[it].y; oa.z += xa[it].z; oa.w += xa[it].w;
+            ob.x += xb[it].x; ob.y += xb[it].y; ob.z += xb[it].z; ob.w += xb[it].w;
+        }
+        *reinterpret_cast<float4*>(dst + (2 * f) * N + q * 4) = oa;
+        *reinterpret_cast<float4*>(dst + (2 * f + 1) * N + q * 4) = ob;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 namespace {
 
 // two-pass LDS FFT: power-of-two planes the one-pass kernels cannot hold
@@ -1409,6 +1629,14 @@ static void fft_dft_split(FftParams& p) {
 }
 
 bool fft_fast_ok(int h, int w) { return lama_is_pow2(h) && lama_is_pow2(w) && h >= 16 && w >= 16 && h <= 128 && w <= 128; }
+// the compile-time two-pass kernels (fp32 planes of 256 x 256); LAMA_FFT_Q=0 (profiling build) keeps the generic two-pass kernels
+bool fq_ok(int h, int w, bool hf) {
+#ifdef LAMA_PROFILING
+    static const int on = lama_env_int("LAMA_FFT_Q", 1);
+    if (!on) return false;
+#endif
+    return h == FQ_N && w == FQ_N && !hf;
+}
 
 int fft_ppw(int h, int w) {
     // planes per workgroup: keep ~256 butterflies per pass busy, LDS <= 64 KiB
@@ -1515,6 +1743,13 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
+    if (fq_ok(p.h, p.w, hf) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4) | (uintptr_t)workspace) & 15) == 0) {
+        hipLaunchKernelGGL(fq_rows_fwd_kernel, dim3(p.nplanes * (FQ_N / 2 / FQ_PAIRS)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_PAIRS * (FQ_N + 1)) * sizeof(float2), st, p, ws);
+        LAMA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(fq_cols_kernel<false>, dim3(p.nplanes * (FQ_N / 2 / FQ_CW)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_N * FQ_CP) * sizeof(float2), st, p, ws);
+        LAMA_CHECK_LAUNCH();
+        return LAMA_OK;
+    }
     if (fft_two_pass_ok(p.h, p.w)) {
         size_t ldsr = ((size_t)p.w + 2 * (size_t)FFT2P_PAIRS * (p.w + 1)) * sizeof(float2);
         size_t ldsc = ((size_t)p.h + 2 * (size_t)FFT2P_COLS * (p.h + 1)) * sizeof(float2);
@@ -1592,6 +1827,13 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
+    if (fq_ok(p.h, p.w, hf) && ((al | (uintptr_t)workspace) & 15) == 0) {
+        hipLaunchKernelGGL(fq_cols_kernel<true>, dim3(p.nplanes * (FQ_N / 2 / FQ_CW)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_N * FQ_CP) * sizeof(float2), st, p, ws);
+        LAMA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(fq_rows_inv_kernel, dim3(p.nplanes * (FQ_N / 2 / FQ_PAIRS)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_PAIRS * (FQ_N + 1)) * sizeof(float2), st, p, (const float2*)ws);
+        LAMA_CHECK_LAUNCH();
+        return LAMA_OK;
+    }
     if (fft_two_pass_ok(p.h, p.w)) {
         size_t ldsr = ((size_t)p.w + 2 * (size_t)FFT2P_PAIRS * (p.w + 1)) * sizeof(float2);
         size_t ldsc = ((size_t)p.h + 2 * (size_t)FFT2P_COLS * (p.h + 1)) * sizeof(float2);
