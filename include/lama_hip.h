@@ -135,7 +135,7 @@ int lama_conv2d_fwd(void* stream, const lama_conv2d_args* args);
  *   lama_winograd_pack_weight: Conv2d weights [Cout, Cin, 3, 3] -> U = G g G^T per channel pair, BatchNorm scale folded, (hi, lo)
  *     split, MFMA A-fragment order; lama_winograd_packed_weight_bytes bytes.
  *   lama_winograd_conv3x3_fwd: args as lama_conv2d_fwd (x, w_packed, bias, act, resid, y, batch, precision, range_flag; kh = kw = 3,
- *     stride = 1, pad = 1, pad_mode = LAMA_PAD_REFLECT); workspace = lama_winograd_workspace_bytes device bytes (the half-inverted
+ *     stride = 1, pad = 1, pad_mode = LAMA_PAD_REFLECT, or (v108) LAMA_PAD_ZERO: the dgrad convs of the reverse pass); workspace = lama_winograd_workspace_bytes device bytes (the half-inverted
  *     transform-domain sums between its two launches).  x, y, resid: 16-byte aligned pointers, batch strides multiples of 4 elements
  *     (else LAMA_ERR_UNSUPPORTED).
  *   lama_winograd_supported: 1 when lama_winograd_conv3x3_fwd takes this (cout, cin, H, W, precision) -- every bound of the launch,
