@@ -34,17 +34,25 @@ struct ActBwdParams {
     int B, act;
 };
 
+// V = 4: 16-byte accesses (per % 4 == 0, 16-byte aligned views -- the host decides)
+template <int V>
 __global__ __launch_bounds__(LAMA_NTHREADS) void act_bwd_kernel(ActBwdParams p) {
-    const long long total = p.per * p.B;
+    typedef float fv_t __attribute__((ext_vector_type(V)));
+    const long long perv = p.per / V, total = perv * p.B;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / p.per);
-        const long long r = i - (long long)b * p.per;
-        const float g = p.g[b * p.g_bs + r], y = p.y[b * p.y_bs + r];
-        float d = 1.0f;
-        if (p.act == LAMA_ACT_RELU) d = y > 0.0f ? 1.0f : 0.0f;
-        else if (p.act == LAMA_ACT_SIGMOID) d = y * (1.0f - y);
-        else if (p.act == LAMA_ACT_TANH) d = 1.0f - y * y;
-        p.out[b * p.out_bs + r] = g * d;
+        const int b = (int)(i / perv);
+        const long long r = (i - (long long)b * perv) * V;
+        const fv_t g = *reinterpret_cast<const fv_t*>(p.g + b * p.g_bs + r), y = *reinterpret_cast<const fv_t*>(p.y + b * p.y_bs + r);
+        fv_t o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            float d = 1.0f;
+            if (p.act == LAMA_ACT_RELU) d = y[e] > 0.0f ? 1.0f : 0.0f;
+            else if (p.act == LAMA_ACT_SIGMOID) d = y[e] * (1.0f - y[e]);
+            else if (p.act == LAMA_ACT_TANH) d = 1.0f - y[e] * y[e];
+            o[e] = g[e] * d;
+        }
+        *reinterpret_cast<fv_t*>(p.out + b * p.out_bs + r) = o;
     }
 }
 
@@ -52,7 +60,9 @@ extern "C" int lama_act_bwd(void* stream, const lama_tensor* g, const lama_tenso
     if (!rf_ok(g) || !rf_ok(y) || !rf_ok(gout) || batch <= 0 || !rf_same(g, y) || !rf_same(g, gout)) return LAMA_ERR_BAD_ARG;
     ActBwdParams p = {(const float*)g->ptr, g->batch_stride, (const float*)y->ptr, y->batch_stride, (float*)gout->ptr, gout->batch_stride,
                       (long long)g->C * g->H * g->W, batch, act};
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(rf_grid(p.per * batch)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    const bool v4 = p.per % 4 == 0 && ((p.g_bs | p.y_bs | p.out_bs) & 3) == 0 && (((uintptr_t)g->ptr | (uintptr_t)y->ptr | (uintptr_t)gout->ptr) & 15) == 0;
+    if (v4) hipLaunchKernelGGL(act_bwd_kernel<4>, dim3(rf_grid(p.per / 4 * batch)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(rf_grid(p.per * batch)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }
@@ -68,12 +78,15 @@ struct AddParams {
     int B;
 };
 
+template <int V>
 __global__ __launch_bounds__(LAMA_NTHREADS) void add_kernel(AddParams p) {
-    const long long total = p.per * p.B;
+    typedef float fv_t __attribute__((ext_vector_type(V)));
+    const long long perv = p.per / V, total = perv * p.B;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i / p.per);
-        const long long r = i - (long long)b * p.per;
-        p.out[b * p.out_bs + r] = p.a[b * p.a_bs + r] + p.b[b * p.b_bs + r];
+        const int b = (int)(i / perv);
+        const long long r = (i - (long long)b * perv) * V;
+        *reinterpret_cast<fv_t*>(p.out + b * p.out_bs + r) =
+            *reinterpret_cast<const fv_t*>(p.a + b * p.a_bs + r) + *reinterpret_cast<const fv_t*>(p.b + b * p.b_bs + r);
     }
 }
 
@@ -81,7 +94,9 @@ extern "C" int lama_add_fwd(void* stream, const lama_tensor* a, const lama_tenso
     if (!rf_ok(a) || !rf_ok(b) || !rf_ok(out) || batch <= 0 || !rf_same(a, b) || !rf_same(a, out)) return LAMA_ERR_BAD_ARG;
     AddParams p = {(const float*)a->ptr, a->batch_stride, (const float*)b->ptr, b->batch_stride, (float*)out->ptr, out->batch_stride,
                    (long long)a->C * a->H * a->W, batch};
-    hipLaunchKernelGGL(add_kernel, dim3(rf_grid(p.per * batch)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    const bool v4 = p.per % 4 == 0 && ((p.a_bs | p.b_bs | p.out_bs) & 3) == 0 && (((uintptr_t)a->ptr | (uintptr_t)b->ptr | (uintptr_t)out->ptr) & 15) == 0;
+    if (v4) hipLaunchKernelGGL(add_kernel<4>, dim3(rf_grid(p.per / 4 * batch)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(add_kernel<1>, dim3(rf_grid(p.per * batch)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }
