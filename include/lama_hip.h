@@ -161,6 +161,14 @@ int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, 
  * resid may be absent.  y [B,C,h,w]. */
 int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* y,
                     int32_t batch, void* workspace, size_t workspace_bytes);
+/* (v108) the same transforms with the ReLU derivative that follows them in the reverse pass of the FourierUnit (refinement.py:163 through
+ * ffc.py:101 and ffc.py:131): out = transform(...) * [mask_y > 0], mask_y laid out like the output (spec for the forward transform, y for the
+ * inverse one).  Only where the compile-time two-pass kernels run (fp32 planes of 256 x 256, 16-byte aligned views): LAMA_ERR_UNSUPPORTED
+ * otherwise, with nothing launched -- the caller then runs the plain transform + lama_act_bwd. */
+int lama_rfft2_masked_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, const lama_tensor* mask_y, int32_t batch,
+                          void* workspace, size_t workspace_bytes);
+int lama_irfft2_masked_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* mask_y, const lama_tensor* y,
+                           int32_t batch, void* workspace, size_t workspace_bytes);
 /* scratch bytes lama_rfft2_fwd / lama_irfft2_fwd / lama_fourier_unit_fwd need for [B,C,h,w] */
 size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, int32_t w);
 

@@ -94,6 +94,10 @@ class LamaLib:
         L.lama_rfft2_fwd.argtypes = [vp, T, T, i32, vp, sz]
         L.lama_irfft2_fwd.restype = C.c_int
         L.lama_irfft2_fwd.argtypes = [vp, T, T, T, i32, vp, sz]
+        L.lama_rfft2_masked_fwd.restype = C.c_int
+        L.lama_rfft2_masked_fwd.argtypes = [vp, T, T, T, i32, vp, sz]
+        L.lama_irfft2_masked_fwd.restype = C.c_int
+        L.lama_irfft2_masked_fwd.argtypes = [vp, T, T, T, T, i32, vp, sz]
         L.lama_fft_workspace_bytes.restype = sz
         L.lama_fft_workspace_bytes.argtypes = [i32] * 4
         L.lama_fourier_unit_workspace_bytes.restype = sz
@@ -256,13 +260,24 @@ class LamaLib:
     def fft_workspace_bytes(self, b, c, h, w) -> int:
         return int(self._l.lama_fft_workspace_bytes(b, c, h, w))
 
-    def rfft2(self, x: Tensor4, spec: Tensor4, batch: int, ws: Optional[torch.Tensor] = None, stream: int = 0):
+    def rfft2(self, x: Tensor4, spec: Tensor4, batch: int, ws: Optional[torch.Tensor] = None, stream: int = 0, mask: Optional[Tensor4] = None):
+        """``mask``: spec *= [mask > 0] in the same launch (lama_rfft2_masked_fwd; LamaError ERR_UNSUPPORTED where no kernel does it)."""
+        if mask is not None:
+            self.check(self._l.lama_rfft2_masked_fwd(stream, C.byref(x), C.byref(spec), C.byref(mask), batch,
+                                                     None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * ws.element_size()),
+                       'lama_rfft2_masked_fwd')
+            return
         self.check(self._l.lama_rfft2_fwd(stream, C.byref(x), C.byref(spec), batch,
                                           None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * ws.element_size()),
                    'lama_rfft2_fwd')
 
     def irfft2(self, spec: Tensor4, resid: Optional[Tensor4], y: Tensor4, batch: int, ws: Optional[torch.Tensor] = None,
-               stream: int = 0):
+               stream: int = 0, mask: Optional[Tensor4] = None):
+        if mask is not None:
+            self.check(self._l.lama_irfft2_masked_fwd(stream, C.byref(spec), None if resid is None else C.byref(resid), C.byref(mask), C.byref(y), batch,
+                                                      None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * ws.element_size()),
+                       'lama_irfft2_masked_fwd')
+            return
         self.check(self._l.lama_irfft2_fwd(stream, C.byref(spec), None if resid is None else C.byref(resid), C.byref(y), batch,
                                            None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel() * ws.element_size()),
                    'lama_irfft2_fwd')

@@ -155,11 +155,24 @@ class _FFCLayerTape:
                                       v(gm_src, 0, cl), B, st)
         # spectral branch: t = x1 + fu(x1), out_g += conv2(t)
         lib.conv2d(L.view(gm, ocl, ocg), bw['wd_2'], L.view(sh['g_t']), B, 1, precision=prec, stream=st)
-        lib.rfft2(L.view(sh['g_t']), L.view(sh['s1']), B, sh['fftws'], st)
-        lib.act_bwd(L.view(sh['s1']), L.view(tape['s2']), L.ACT_RELU, L.view(sh['s3']), B, st)
+        # the two ReLU derivatives of the branch ride in the transforms where a kernel does that (256 x 256 planes: lama_*_masked_fwd, v108)
+        fused = sh.get('fft_mask', True)
+        if fused:
+            try:
+                lib.rfft2(L.view(sh['g_t']), L.view(sh['s3']), B, sh['fftws'], st, mask=L.view(tape['s2']))
+            except LamaError as e:
+                if e.code != L.ERR_UNSUPPORTED:
+                    raise
+                fused = sh['fft_mask'] = False
+        if not fused:
+            lib.rfft2(L.view(sh['g_t']), L.view(sh['s1']), B, sh['fftws'], st)
+            lib.act_bwd(L.view(sh['s1']), L.view(tape['s2']), L.ACT_RELU, L.view(sh['s3']), B, st)
         lib.conv2d(L.view(sh['s3']), bw['wd_fu'], L.view(sh['s1']), B, 1, precision=prec, stream=st)
-        lib.irfft2(L.view(sh['s1']), L.view(sh['g_t']), L.view(sh['g_x1']), B, sh['fftws'], st)          # + g_t: the identity path of t
-        lib.act_bwd(L.view(sh['g_x1']), L.view(tape['x1']), L.ACT_RELU, L.view(sh['g_x1']), B, st)
+        if fused:
+            lib.irfft2(L.view(sh['s1']), L.view(sh['g_t']), L.view(sh['g_x1']), B, sh['fftws'], st, mask=L.view(tape['x1']))
+        else:
+            lib.irfft2(L.view(sh['s1']), L.view(sh['g_t']), L.view(sh['g_x1']), B, sh['fftws'], st)          # + g_t: the identity path of t
+            lib.act_bwd(L.view(sh['g_x1']), L.view(tape['x1']), L.ACT_RELU, L.view(sh['g_x1']), B, st)
         # global input: through convg2l (3x3) and through conv1 (1x1)
         lib.conv2d(L.view(gm, 0, ocl), bw['wd_g2l'], L.view(sh['gp_g']), B, 3, 1, 2, L.PAD_ZERO, False, None, L.ACT_NONE, precision=prec, stream=st)
         lib.conv2d(L.view(sh['g_x1']), bw['wd_1'], L.view(sh['g1']), B, 1, precision=prec, stream=st)

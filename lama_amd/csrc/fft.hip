@@ -173,6 +173,8 @@ struct FftParams {
     int prio;            // raise the wave priority (s_setprio): these launches are the short links of the spectral branch, which runs beside
                          // the local 3x3 conv of the other stream on the same SIMDs
     long long* trace;    // profiling tools only (LAMA_FFT_TRACE): 16 int64 per workgroup, 100 MHz ticks at the phase boundaries
+    const float* mask;   // round 4 (fq kernels only): the output is multiplied by [mask > 0] -- the ReLU derivative that follows the transform in
+    long long mask_bstride;   // the reverse pass (forward: a tensor laid out like spec; inverse: like y)
 };
 
 template <bool INV>
@@ -1483,6 +1485,9 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fq_cols_kernel(FftParams p, flo
     float* sre = (float*)p.spec + (long long)b * p.spec_bstride + (long long)(2 * c) * per_plane;
     float* sim = sre + per_plane;
     float2* wp = ws + (long long)plane * N * wh;
+    const float* mre = (!INV && p.mask) ? p.mask + (long long)b * p.mask_bstride + (long long)(2 * c) * per_plane : nullptr;
+    const float* mim = mre ? mre + per_plane : nullptr;
+    (void)mim;
     if constexpr (!INV) {
         // 256 rows x QW float4 (two columns each): one aligned 128 / 256-byte segment per row
         float4 v[QW];
@@ -1498,6 +1503,18 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fq_cols_kernel(FftParams p, flo
             P[y * CP + 2 * q] = make_float2(v[it].x, v[it].y);
             P[y * CP + 2 * q + 1] = make_float2(v[it].z, v[it].w);
         }
+        // the mask values of this thread's output items, requested before the transform (at the stores every load would wait for the store
+        // before it -- the planes may alias for all the compiler knows: 56 instead of 32 us)
+        float mkr[N * CW / LAMA_NTHREADS], mki[N * CW / LAMA_NTHREADS], mnr[N * CW / LAMA_NTHREADS], mni[N * CW / LAMA_NTHREADS];   // (kk is the same for all items of a thread)
+        if (mre) {
+#pragma unroll
+            for (int it = 0; it < N * CW / LAMA_NTHREADS; ++it) {
+                const int item = tid + it * LAMA_NTHREADS, u = item >> CL, kk = item & (CW - 1);
+                mkr[it] = mre[(long long)u * wf + k0 + kk];
+                mki[it] = mim[(long long)u * wf + k0 + kk];
+                if (k0 + kk == 0) { mnr[it] = mre[(long long)u * wf + wh]; mni[it] = mim[(long long)u * wf + wh]; }
+            }
+        }
         __syncthreads();
         fq_fft_cols<false>(P, tw);
         // rows u, 16 columns each: 64-byte segments of the Re and of the Im plane (the layout lama_tensor fixes)
@@ -1508,12 +1525,21 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fq_cols_kernel(FftParams p, flo
             if (k0 + kk == 0) {       // the packed column: DC = Hermitian part, Nyquist = anti-Hermitian part / i
                 const float2 cc = v2, cm = P[((N - u) & (N - 1)) * CP];
                 v2 = make_float2(0.5f * (cc.x + cm.x), 0.5f * (cc.y - cm.y));
-                const float2 ny = make_float2(0.5f * (cc.y + cm.y), 0.5f * (cm.x - cc.x));
-                sre[(long long)u * wf + wh] = ny.x * p.scale;
-                sim[(long long)u * wf + wh] = ny.y * p.scale;
+                float2 ny = make_float2(0.5f * (cc.y + cm.y) * p.scale, 0.5f * (cm.x - cc.x) * p.scale);
+                if (mre) {
+                    ny.x = mnr[it] > 0.0f ? ny.x : 0.0f;
+                    ny.y = mni[it] > 0.0f ? ny.y : 0.0f;
+                }
+                sre[(long long)u * wf + wh] = ny.x;
+                sim[(long long)u * wf + wh] = ny.y;
             }
-            sre[(long long)u * wf + k0 + kk] = v2.x * p.scale;
-            sim[(long long)u * wf + k0 + kk] = v2.y * p.scale;
+            float2 ov = make_float2(v2.x * p.scale, v2.y * p.scale);
+            if (mre) {
+                ov.x = mkr[it] > 0.0f ? ov.x : 0.0f;
+                ov.y = mki[it] > 0.0f ? ov.y : 0.0f;
+            }
+            sre[(long long)u * wf + k0 + kk] = ov.x;
+            sim[(long long)u * wf + k0 + kk] = ov.y;
         }
     } else {
         fft_init_twiddles<true>(tw, N);
@@ -1575,6 +1601,16 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fq_rows_inv_kernel(FftParams p,
             xb[it] = *reinterpret_cast<const float4*>(rs + (2 * f + 1) * N + q * 4);
         }
     }
+    float4 ma[2], mb[2];
+    if (p.mask) {
+        const float* mk = p.mask + (long long)b * p.mask_bstride + obase;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + it * LAMA_NTHREADS, f = item >> 6, q = item & 63;
+            ma[it] = *reinterpret_cast<const float4*>(mk + (2 * f) * N + q * 4);
+            mb[it] = *reinterpret_cast<const float4*>(mk + (2 * f + 1) * N + q * 4);
+        }
+    }
     fft_init_twiddles<true>(tw, N);
 #pragma unroll
     for (int it = 0; it < NP * wh / LAMA_NTHREADS; ++it) {
@@ -1602,6 +1638,10 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fq_rows_inv_kernel(FftParams p,
         if (rs) {
             oa.x += xa[it].x; oa.y += xa[it].y; oa.z += xa[it].z; oa.w += xa[it].w;
             ob.x += xb[it].x; ob.y += xb[it].y; ob.z += xb[it].z; ob.w += xb[it].w;
+        }
+        if (p.mask) {
+            oa.x = ma[it].x > 0.0f ? oa.x : 0.0f; oa.y = ma[it].y > 0.0f ? oa.y : 0.0f; oa.z = ma[it].z > 0.0f ? oa.z : 0.0f; oa.w = ma[it].w > 0.0f ? oa.w : 0.0f;
+            ob.x = mb[it].x > 0.0f ? ob.x : 0.0f; ob.y = mb[it].y > 0.0f ? ob.y : 0.0f; ob.z = mb[it].z > 0.0f ? ob.z : 0.0f; ob.w = mb[it].w > 0.0f ? ob.w : 0.0f;
         }
         *reinterpret_cast<float4*>(dst + (2 * f) * N + q * 4) = oa;
         *reinterpret_cast<float4*>(dst + (2 * f + 1) * N + q * 4) = ob;
@@ -1697,8 +1737,8 @@ extern "C" size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, 
         else hipLaunchKernelGGL((name<FFT_UNPAREN targs, false>), grid, blk, lds, st, __VA_ARGS__);     \
     } while (0)
 
-extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch,
-                              void* workspace, size_t workspace_bytes) {
+static int rfft2_impl(void* stream, const lama_tensor* x, const lama_tensor* spec, const lama_tensor* mask, int32_t batch,
+                      void* workspace, size_t workspace_bytes) {
     if (!fft_args_ok(x, spec, batch)) return LAMA_ERR_BAD_ARG;
     if (x->dtype != spec->dtype || (x->dtype != LAMA_DT_F32 && x->dtype != LAMA_DT_F16)) return LAMA_ERR_UNSUPPORTED;
     const bool hf = x->dtype == LAMA_DT_F16;
@@ -1715,6 +1755,12 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     p.scale = (float)(1.0 / sqrt((double)p.h * (double)p.w));
     hipStream_t st = (hipStream_t)stream;
     const bool spec_al = (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * es)) & amask) == 0;
+    if (mask) {   // only the compile-time two-pass kernels apply a mask: anything else is the caller's separate lama_act_bwd launch
+        if (!mask->ptr || mask->dtype != LAMA_DT_F32 || mask->C != spec->C || mask->H != spec->H || mask->W != spec->W) return LAMA_ERR_BAD_ARG;
+        if (!(fq_ok(p.h, p.w, hf) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4) | (uintptr_t)workspace) & 15) == 0)) return LAMA_ERR_UNSUPPORTED;
+        p.mask = (const float*)mask->ptr;
+        p.mask_bstride = mask->batch_stride;
+    }
     if (fft_fast_ok(p.h, p.w) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * es)) & amask) == 0) {
         p.ppw = fft_ppw(p.h, p.w);
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
@@ -1774,8 +1820,8 @@ extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_ten
     return LAMA_OK;
 }
 
-extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* y,
-                               int32_t batch, void* workspace, size_t workspace_bytes) {
+static int irfft2_impl(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* mask, const lama_tensor* y,
+                       int32_t batch, void* workspace, size_t workspace_bytes) {
     if (!fft_args_ok(y, spec, batch)) return LAMA_ERR_BAD_ARG;
     const bool has_r = resid && resid->ptr;
     if (has_r && (resid->C != y->C || resid->H != y->H || resid->W != y->W)) return LAMA_ERR_BAD_ARG;
@@ -1799,6 +1845,13 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     uintptr_t al = (uintptr_t)y->ptr | (uintptr_t)(y->batch_stride * es);
     if (has_r) al |= (uintptr_t)resid->ptr | (uintptr_t)(resid->batch_stride * es);
     const bool spec_al = (((uintptr_t)spec->ptr | (uintptr_t)(spec->batch_stride * es)) & amask) == 0;
+    if (mask) {
+        if (!mask->ptr || mask->dtype != LAMA_DT_F32 || mask->C != y->C || mask->H != y->H || mask->W != y->W) return LAMA_ERR_BAD_ARG;
+        al |= (uintptr_t)mask->ptr | (uintptr_t)(mask->batch_stride * 4);
+        if (!(fq_ok(p.h, p.w, hf) && ((al | (uintptr_t)workspace) & 15) == 0)) return LAMA_ERR_UNSUPPORTED;
+        p.mask = (const float*)mask->ptr;
+        p.mask_bstride = mask->batch_stride;
+    }
     if (fft_fast_ok(p.h, p.w) && (al & amask) == 0) {
         p.ppw = fft_ppw(p.h, p.w);
         size_t lds = fft_lds_bytes(p.h, p.w, p.ppw);
@@ -1856,4 +1909,24 @@ extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama
     else hipLaunchKernelGGL(dft_rows_inv_kernel<false>, dim3((unsigned)lama_ceil_div64(nrows, DFT_ROWS_PER_WG)), dim3(LAMA_NTHREADS), lds1, st, p, (const float2*)ws);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
+}
+
+extern "C" int lama_rfft2_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch, void* workspace, size_t workspace_bytes) {
+    return rfft2_impl(stream, x, spec, nullptr, batch, workspace, workspace_bytes);
+}
+extern "C" int lama_irfft2_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* y, int32_t batch, void* workspace,
+                               size_t workspace_bytes) {
+    return irfft2_impl(stream, spec, resid, nullptr, y, batch, workspace, workspace_bytes);
+}
+// (v108) the transforms of the reverse pass with the ReLU derivative that follows them: out = transform(...) * [mask_y > 0].  Only where the
+// compile-time two-pass kernels run (fp32 planes of 256 x 256, 16-byte aligned views); LAMA_ERR_UNSUPPORTED otherwise, nothing launched.
+extern "C" int lama_rfft2_masked_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, const lama_tensor* mask_y, int32_t batch,
+                                     void* workspace, size_t workspace_bytes) {
+    if (!mask_y) return LAMA_ERR_BAD_ARG;
+    return rfft2_impl(stream, x, spec, mask_y, batch, workspace, workspace_bytes);
+}
+extern "C" int lama_irfft2_masked_fwd(void* stream, const lama_tensor* spec, const lama_tensor* resid, const lama_tensor* mask_y, const lama_tensor* y,
+                                      int32_t batch, void* workspace, size_t workspace_bytes) {
+    if (!mask_y) return LAMA_ERR_BAD_ARG;
+    return irfft2_impl(stream, spec, resid, mask_y, y, batch, workspace, workspace_bytes);
 }

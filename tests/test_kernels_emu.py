@@ -227,6 +227,31 @@ def test_rfft2_irfft2_emulated(hw):
     assert torch.allclose(y2, ref2 - resid, atol=tol, rtol=1e-4)
 
 
+def test_fft_masked_entries_emulated():
+    """lama_rfft2_masked_fwd / lama_irfft2_masked_fwd (v108): the transform times [mask > 0] in one launch on 256 x 256 planes, LAMA_ERR_UNSUPPORTED
+    (nothing launched) elsewhere."""
+    lib = emu_lib()
+    g = torch.Generator().manual_seed(77)
+    B, Cn, h, w = 1, 2, 256, 256
+    x = torch.randn(B, Cn, h, w, generator=g)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4)
+    ms = torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g)
+    spec, spec_m = torch.zeros(B, 2 * Cn, h, w // 2 + 1), torch.full((B, 2 * Cn, h, w // 2 + 1), 3.0)
+    lib.rfft2(L.view(x), L.view(spec), B, ws)
+    lib.rfft2(L.view(x), L.view(spec_m), B, ws, mask=L.view(ms))
+    assert torch.equal(spec_m, spec * (ms > 0))
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g))
+    resid, my = torch.randn(B, Cn, h, w, generator=g), torch.randn(B, Cn, h, w, generator=g)
+    y, y_m = torch.zeros(B, Cn, h, w), torch.full((B, Cn, h, w), 3.0)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y), B, ws)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y_m), B, ws, mask=L.view(my))
+    assert torch.equal(y_m, y * (my > 0))
+    xs, ss = torch.randn(1, 2, 64, 64, generator=g), torch.zeros(1, 4, 64, 33)
+    with pytest.raises(L.LamaError) as ei:
+        lib.rfft2(L.view(xs), L.view(ss), 1, ws, mask=L.view(torch.ones(1, 4, 64, 33)))
+    assert ei.value.code == L.ERR_UNSUPPORTED and float(ss.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('hw_seq', [(64, 1), (64, 2), (64, 3), (128, 3)], ids=lambda s: f'{s[0]}x{s[0]}seq{s[1]}')
 def test_fft_sequential_planes_emulated(hw_seq, monkeypatch):
     """Sized one-plane kernels walking SEQ consecutive planes per workgroup with the next plane prefetched (LAMA_FFT_SEQ)."""

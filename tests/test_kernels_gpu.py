@@ -231,6 +231,30 @@ def test_rfft2_irfft2(lib, hw):
     assert torch.allclose(y.cpu(), ref2, atol=tol, rtol=1e-4), float((y.cpu() - ref2).abs().max())
 
 
+def test_fft_masked_entries(lib):
+    """lama_rfft2_masked_fwd / lama_irfft2_masked_fwd (v108) on 256 x 256 planes against transform + separate mask, channel views of wider buffers."""
+    g = torch.Generator().manual_seed(77)
+    B, Cn, h, w = 2, 192, 256, 256
+    wide = torch.randn(B, Cn + 2, h, w, generator=g).to(DEV)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4, device=DEV)
+    ms = torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g).to(DEV)
+    spec, spec_m = torch.zeros(B, 2 * Cn, h, w // 2 + 1, device=DEV), torch.full((B, 2 * Cn, h, w // 2 + 1), 3.0, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, ws, stream=st)
+    lib.rfft2(L.view(wide, 1, Cn), L.view(spec_m), B, ws, stream=st, mask=L.view(ms))
+    assert torch.equal(spec_m, spec * (ms > 0))
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g)).to(DEV)
+    resid, my = torch.randn(B, Cn, h, w, generator=g).to(DEV), torch.randn(B, Cn + 1, h, w, generator=g).to(DEV)
+    y, y_m = torch.zeros(B, Cn, h, w, device=DEV), torch.full((B, Cn, h, w), 3.0, device=DEV)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y), B, ws, stream=st)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y_m), B, ws, stream=st, mask=L.view(my, 1, Cn))
+    assert torch.equal(y_m, y * (my[:, 1:] > 0))
+    with pytest.raises(L.LamaError) as ei:
+        lib.rfft2(L.view(wide[:, :, :64, :64].contiguous(), 0, 4), L.view(torch.zeros(B, 8, 64, 33, device=DEV)), B, ws, stream=st,
+                  mask=L.view(torch.ones(B, 8, 64, 33, device=DEV)))
+    assert ei.value.code == L.ERR_UNSUPPORTED
+
+
 @pytest.mark.parametrize('n_seq', [(64, 1), (64, 2), (64, 3), (128, 2), (128, 3)], ids=lambda s: f'{s[0]}seq{s[1]}')
 def test_fft_sequential_planes(lib_forced, n_seq, monkeypatch):
     lib = lib_forced      # LAMA_FFT_SEQ / LAMA_FFT_INPLACE exist in the profiling build only
