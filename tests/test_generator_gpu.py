@@ -155,6 +155,37 @@ def test_biglama_512_batch8_all_images(big):
         gen._plans.clear()
 
 
+def test_biglama_in_place_plan_is_bit_identical(big):
+    """Round 4: the resnet blocks in place, t over x1, the Winograd partial sums in the FourierUnit's spectra (348 -> 211 MB per residual layer,
+    DESIGN.md 3) -- every overwritten operand is read by the thread that writes it, so the four-buffer plan gives the SAME bits; 4 x 512^2
+    (128 pixel tiles: the fused conv1 / Winograd one-stream plan of the split precisions), eager and graph replay, twice (dirty buffers)."""
+    cfg, sd, gen, TOL = big
+    batch = O.make_synthetic_batch(4, 512, 512, seed=41)
+    xd = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
+    outs = []
+    try:
+        for flag in (False, True):
+            gen.inplace_residual = gen.alias_t = gen.alias_wino = flag
+            gen._plans.clear()
+            outs.append(gen(xd).clone())
+            outs.append(gen(xd).clone())
+            plan = next(iter(gen._plans.values()))
+            sc = plan['scratch']
+            if flag:
+                assert sc['t'].data_ptr() == sc['x1'].data_ptr()
+                if sc.get('wino') is not None and plan['side'] is None:
+                    assert sc['wino'].data_ptr() == sc['ws'].data_ptr()
+            gen.use_graph = True
+            try:
+                outs.append(gen(xd).clone())
+            finally:
+                gen.use_graph = False
+    finally:
+        gen.inplace_residual = gen.alias_t = gen.alias_wino = True
+        gen._plans.clear()
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+
+
 def test_training_module_properties_at_configs1_size():
     """DefaultInpaintingTrainingModule.forward at 8x512x512 (BASELINE configs[1]) through properties that need no CPU pass: outside the
     hole the inpainted image IS the input (bitwise: inpainted = m pred + (1 - m) img, trainers/default.py:71), inside it is the
