@@ -121,9 +121,10 @@ class KernelTimer:
             return fn(*a, **kw)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn(*a, **kw)
+        r = fn(*a, **kw)
         e1.record()
         self.records.setdefault(key, []).append((e0, e1))
+        return r
 
     def conv2d(self, x, w_packed, y, batch, k, *a, **kw):
         x2 = kw.get("x2", a[7] if len(a) > 7 else None)
@@ -490,6 +491,8 @@ def main():
     model.generator.defer_range_check = True
     if 'LAMA_INPLACE' in os.environ:          # same-box A/B of the in-place residual state / t over x1 (tools/session.sh ab:LAMA_INPLACE=0,1)
         model.generator.inplace_residual = model.generator.alias_t = bool(int(os.environ['LAMA_INPLACE']))
+    if 'LAMA_DEFER_OUT' in os.environ:        # ... of the Winograd output transform inside the next layer's rfft2 launch
+        model.generator.defer_wino_out = bool(int(os.environ['LAMA_DEFER_OUT']))
     if 'LAMA_ALIAS_WINO' in os.environ:       # ... of the Winograd partial sums in the FourierUnit's (dead) spectra
         model.generator.alias_wino = bool(int(os.environ['LAMA_ALIAS_WINO']))
     for _ in range(args.warmup):
@@ -595,6 +598,11 @@ def main():
         model.generator.overlap_streams = False     # per-kernel events need every launch on the current stream
         from lama_amd import ffc as _ffc2
         _ffc2._DEFAULT_EXEC.cooperative_serial = True   # ... of the same kernel geometry as the timed region's (FFC.launch sets the flag when it forks)
+        # per-UNIT times: in the timed region the Winograd output transform of layer l rides in the rfft2 launch of layer l + 1
+        # (generator.defer_wino_out); here every unit runs its own launches, so that `fourier_unit_*` is the FourierUnit alone and
+        # `conv3x3_cin512_*` the local conv with both of its launches (the fused launch is in profiles/*kernel_stats*.csv)
+        defer_timed = model.generator.defer_wino_out
+        model.generator.defer_wino_out = False
         model.generator._plans.clear()
         step(collect=False)                         # rank 0 only: no collective in here (the other ranks are done)
         torch.cuda.synchronize()
@@ -605,6 +613,7 @@ def main():
         timer.on = False
         kern = timer.summary()
         _ffc2._DEFAULT_EXEC.cooperative_serial = False
+        model.generator.defer_wino_out = defer_timed
         model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # back to the timed configuration
         model.generator._plans.clear()
         dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])

@@ -108,6 +108,9 @@ typedef struct lama_conv2d_args {
     int32_t flags;
 } lama_conv2d_args;
 #define LAMA_CONV_COOPERATIVE 1
+/* (v108, lama_winograd_conv3x3_fwd only) launch the GEMM half only; the caller owes the output transform -- lama_winograd_out_fwd or
+ * lama_rfft2_winograd_out_fwd with the SAME arguments and workspace -- before anything reads y */
+#define LAMA_CONV_DEFER_OUT 2
 
 /* order[k] = the input channel of conv1 that sits at packed K position k (0 <= k < 384) of lama_conv2d_args.fuse1_w */
 void lama_fuse1_channel_order(int32_t* order);
@@ -150,6 +153,18 @@ int32_t lama_winograd_supported(int32_t cout, int32_t cin, int32_t H, int32_t W,
 int lama_winograd_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t precision, void* dst);
 size_t lama_winograd_workspace_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W);
 int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* args, void* workspace, size_t workspace_bytes);
+/* (v108) the second launch of lama_winograd_conv3x3_fwd on its own (after a call with LAMA_CONV_DEFER_OUT), and the same work inside the
+ * rfft2 launch of the NEXT FFC layer (ffc.py:86 of layer l + 1 with ffc.py:220,251-255,288 of layer l): both are memory-bound and independent, and
+ * the FFT workgroups leave the HBM idle while they transform.  64 x 64 fp32 planes only (LAMA_ERR_UNSUPPORTED otherwise, nothing launched). */
+/* lama_fourier_unit_winograd_out_fwd: lama_fourier_unit_fwd whose first launch is lama_rfft2_winograd_out_fwd (or, where that is unsupported,
+ * lama_winograd_out_fwd followed by the plain FourierUnit): what the host mirror calls for layer l + 1 when layer l deferred its transform. */
+int lama_winograd_out_fwd(void* stream, const lama_conv2d_args* args, void* workspace, size_t workspace_bytes);
+int lama_rfft2_winograd_out_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch, void* workspace, size_t workspace_bytes,
+                                const lama_conv2d_args* wino_args, void* wino_workspace, size_t wino_workspace_bytes);
+int lama_fourier_unit_winograd_out_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias, const lama_tensor* y,
+                                       int32_t batch, int32_t add_input, int32_t precision, void* workspace, size_t workspace_bytes,
+                                       uint32_t* range_flag, const lama_conv2d_args* wino_args, void* wino_workspace,
+                                       size_t wino_workspace_bytes);
 
 /* torch.fft.rfftn(x, dim=(-2,-1), norm='ortho') followed by the Re/Im channel interleave
  * (ffc.py:86-89): x [B,C,h,w] -> spec [B,2C,h,w/2+1], channel 2c = Re, 2c+1 = Im. */

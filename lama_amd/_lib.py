@@ -16,6 +16,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 CONV_COOPERATIVE = 1
+CONV_DEFER_OUT = 2          # lama_winograd_conv3x3_fwd: the GEMM launch only (include/lama_hip.h)
 DT_F32, DT_F16 = 0, 1
 ABI_VERSION = 108      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
@@ -94,6 +95,10 @@ class LamaLib:
         L.lama_rfft2_fwd.argtypes = [vp, T, T, i32, vp, sz]
         L.lama_irfft2_fwd.restype = C.c_int
         L.lama_irfft2_fwd.argtypes = [vp, T, T, T, i32, vp, sz]
+        L.lama_winograd_out_fwd.restype = C.c_int
+        L.lama_winograd_out_fwd.argtypes = [vp, C.POINTER(Conv2dArgs), vp, sz]
+        L.lama_rfft2_winograd_out_fwd.restype = C.c_int
+        L.lama_rfft2_winograd_out_fwd.argtypes = [vp, T, T, i32, vp, sz, C.POINTER(Conv2dArgs), vp, sz]
         L.lama_rfft2_masked_fwd.restype = C.c_int
         L.lama_rfft2_masked_fwd.argtypes = [vp, T, T, T, i32, vp, sz]
         L.lama_irfft2_masked_fwd.restype = C.c_int
@@ -104,6 +109,8 @@ class LamaLib:
         L.lama_fourier_unit_workspace_bytes.argtypes = [i32] * 4
         L.lama_fourier_unit_fwd.restype = C.c_int
         L.lama_fourier_unit_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz, vp]
+        L.lama_fourier_unit_winograd_out_fwd.restype = C.c_int
+        L.lama_fourier_unit_winograd_out_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz, vp, C.POINTER(Conv2dArgs), vp, sz]
         L.lama_mask_compose_fwd.restype = C.c_int
         L.lama_mask_compose_fwd.argtypes = [vp, T, T, T, i32]
         L.lama_blend_fwd.restype = C.c_int
@@ -237,7 +244,9 @@ class LamaLib:
 
     def winograd_conv3x3(self, x: Tensor4, w_packed: torch.Tensor, y: Tensor4, batch: int, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
                          act: int = ACT_NONE, resid: Optional[Tensor4] = None, precision: int = PREC_F16X3, stream: int = 0,
-                         range_flag: Optional[torch.Tensor] = None, pad_mode: int = PAD_REFLECT):
+                         range_flag: Optional[torch.Tensor] = None, pad_mode: int = PAD_REFLECT, defer_out: bool = False):
+        """``defer_out`` (v108): only the GEMM launch; returns the argument block the caller hands to ``winograd_out`` / ``rfft2_wino_out``
+        (with the same workspace) before anything reads y."""
         a = Conv2dArgs()
         a.x, a.w_packed = x, w_packed.data_ptr()
         a.kh = a.kw = 3
@@ -248,7 +257,21 @@ class LamaLib:
             a.resid = resid
         a.y, a.batch, a.precision = y, batch, precision
         a.range_flag = None if range_flag is None else range_flag.data_ptr()
+        a.flags = CONV_DEFER_OUT if defer_out else 0
         self.check(self._l.lama_winograd_conv3x3_fwd(stream, C.byref(a), ws.data_ptr(), ws.numel() * ws.element_size()), 'lama_winograd_conv3x3_fwd')
+        return a if defer_out else None
+
+    def winograd_out(self, args: 'Conv2dArgs', ws: torch.Tensor, stream: int = 0):
+        """The output transform a ``winograd_conv3x3(..., defer_out=True)`` call left out (lama_winograd_out_fwd)."""
+        self.check(self._l.lama_winograd_out_fwd(stream, C.byref(args), ws.data_ptr(), ws.numel() * ws.element_size()), 'lama_winograd_out_fwd')
+
+    def rfft2_wino_out(self, x: Tensor4, spec: Tensor4, batch: int, ws: Optional[torch.Tensor], wino_args: 'Conv2dArgs', wino_ws: torch.Tensor,
+                       stream: int = 0):
+        """rfft2 + the deferred Winograd output transform of the layer before in one launch (lama_rfft2_winograd_out_fwd; ERR_UNSUPPORTED where
+        no kernel does it: the caller then runs the two separately)."""
+        self.check(self._l.lama_rfft2_winograd_out_fwd(stream, C.byref(x), C.byref(spec), batch, None if ws is None else ws.data_ptr(),
+                                                       0 if ws is None else ws.numel() * ws.element_size(), C.byref(wino_args), wino_ws.data_ptr(),
+                                                       wino_ws.numel() * wino_ws.element_size()), 'lama_rfft2_winograd_out_fwd')
 
     def fuse1_channel_order(self) -> torch.Tensor:
         """Input-channel order of a conv1 weight that rides in another launch's epilogue (lama_fuse1_channel_order)."""
@@ -286,7 +309,18 @@ class LamaLib:
         return int(self._l.lama_fourier_unit_workspace_bytes(b, c, h, w))
 
     def fourier_unit(self, x: Tensor4, w_packed: torch.Tensor, bias: torch.Tensor, y: Tensor4, batch: int, add_input: bool,
-                     ws: torch.Tensor, precision: int = PREC_F32, stream: int = 0, range_flag: Optional[torch.Tensor] = None):
+                     ws: torch.Tensor, precision: int = PREC_F32, stream: int = 0, range_flag: Optional[torch.Tensor] = None,
+                     wino_out: Optional[tuple] = None):
+        """``wino_out`` = (argument block of a ``winograd_conv3x3(..., defer_out=True)`` call, its workspace): that conv's output transform runs
+        inside this FourierUnit's rfft2 launch (lama_fourier_unit_winograd_out_fwd, v108)."""
+        if wino_out is not None:
+            wa, wws = wino_out
+            self.check(self._l.lama_fourier_unit_winograd_out_fwd(stream, C.byref(x), w_packed.data_ptr(), bias.data_ptr(), C.byref(y), batch,
+                                                                  int(add_input), precision, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                                                  None if range_flag is None else range_flag.data_ptr(), C.byref(wa),
+                                                                  wws.data_ptr(), wws.numel() * wws.element_size()),
+                       'lama_fourier_unit_winograd_out_fwd')
+            return
         self.check(self._l.lama_fourier_unit_fwd(stream, C.byref(x), w_packed.data_ptr(), bias.data_ptr(), C.byref(y), batch,
                                                  int(add_input), precision, ws.data_ptr(), ws.numel() * ws.element_size(),
                                                  None if range_flag is None else range_flag.data_ptr()),

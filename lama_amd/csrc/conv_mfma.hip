@@ -513,6 +513,33 @@ extern "C" int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* a
     return LAMA_ERR_UNSUPPORTED;
 }
 
+// the checks of lama_winograd_conv3x3_fwd that the second launch needs again
+static int wino_args_ok(const lama_conv2d_args* a) {
+    if (!a || !tensor_ok(a->x) || !tensor_ok(a->y) || a->batch <= 0) return LAMA_ERR_BAD_ARG;
+    if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad != 1 || a->transposed) return LAMA_ERR_UNSUPPORTED;
+    if (a->y.dtype != LAMA_DT_F32 || (a->resid.ptr && a->resid.dtype != LAMA_DT_F32)) return LAMA_ERR_UNSUPPORTED;
+    if (a->x.H != a->y.H || a->x.W != a->y.W) return LAMA_ERR_BAD_ARG;
+    if (a->resid.ptr && (a->resid.C != a->y.C || a->resid.H != a->y.H || a->resid.W != a->y.W)) return LAMA_ERR_BAD_ARG;
+    if ((((uintptr_t)a->y.ptr | (uintptr_t)a->resid.ptr) & 15) != 0 || a->y.batch_stride % 4 != 0 || (a->resid.ptr && a->resid.batch_stride % 4 != 0))
+        return LAMA_ERR_UNSUPPORTED;
+    if (a->precision != LAMA_PREC_BF16X3 && a->precision != LAMA_PREC_F16X3) return LAMA_ERR_UNSUPPORTED;
+    return LAMA_OK;
+}
+
+// the output transform's launch parameters (a WoParams of wino_out_dev.inc) from the arguments of the first launch; used by
+// lama_rfft2_winograd_out_fwd (fft.hip)
+int lama_wino_out_params(const lama_conv2d_args* a, void* workspace, size_t workspace_bytes, void* out) {
+    const int rc = wino_args_ok(a);
+    if (rc) return rc;
+    return lama_cb_wino_out_params_f16x3(a, workspace, workspace_bytes, out);      // the same for both split precisions
+}
+
+extern "C" int lama_winograd_out_fwd(void* stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes) {
+    const int rc = wino_args_ok(a);
+    if (rc) return rc;
+    return lama_cb_wino_out_fwd_f16x3((hipStream_t)stream, a, workspace, workspace_bytes);
+}
+
 extern "C" void lama_fuse1_channel_order(int32_t* order) {
     for (int kq = 0; kq < 24; ++kq)
         for (int kh = 0; kh < 2; ++kh)

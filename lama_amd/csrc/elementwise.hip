@@ -241,9 +241,10 @@ extern "C" size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, in
     return 2 * spec + lama_fft_workspace_bytes(batch, C, h, w);
 }
 
-extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
-                                     const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
-                                     void* workspace, size_t workspace_bytes, uint32_t* range_flag) {
+static int fourier_unit_impl(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
+                             const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
+                             void* workspace, size_t workspace_bytes, uint32_t* range_flag,
+                             const lama_conv2d_args* wino_args, void* wino_ws, size_t wino_ws_bytes) {
     if (!x || !y || !x->ptr || !y->ptr || !w_packed || batch <= 0) return LAMA_ERR_BAD_ARG;
     if (x->C != y->C || x->H != y->H || x->W != y->W) return LAMA_ERR_BAD_ARG;
     const int C = x->C, h = x->H, w = x->W, wf = w / 2 + 1;
@@ -255,7 +256,17 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
     lama_tensor s2 = {ws + spec_bytes, (int64_t)2 * C * h * wf, 2 * C, h, wf, x->dtype};
     void* fws = ws + 2 * spec_bytes;
     size_t fws_bytes = workspace_bytes - 2 * spec_bytes;
-    int rc = lama_rfft2_fwd(stream, x, &s1, batch, fws, fws_bytes);
+    int rc;
+    if (wino_args) {      // the deferred output transform of the Winograd conv of the layer before: inside the rfft2 launch where a kernel does that
+        rc = lama_rfft2_winograd_out_fwd(stream, x, &s1, batch, fws, fws_bytes, wino_args, wino_ws, wino_ws_bytes);
+        if (rc == LAMA_ERR_UNSUPPORTED) {
+            rc = lama_winograd_out_fwd(stream, wino_args, wino_ws, wino_ws_bytes);
+            if (rc) return rc;
+            rc = lama_rfft2_fwd(stream, x, &s1, batch, fws, fws_bytes);
+        }
+    } else {
+        rc = lama_rfft2_fwd(stream, x, &s1, batch, fws, fws_bytes);
+    }
     if (rc) return rc;
     lama_conv2d_args a;
     memset(&a, 0, sizeof(a));
@@ -272,5 +283,22 @@ extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const v
     rc = lama_conv2d_fwd(stream, &a);
     if (rc) return rc;
     return lama_irfft2_fwd(stream, &s2, add_input ? x : nullptr, y, batch, fws, fws_bytes);
+}
+
+extern "C" int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
+                                     const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
+                                     void* workspace, size_t workspace_bytes, uint32_t* range_flag) {
+    return fourier_unit_impl(stream, x, w_packed, bias, y, batch, add_input, precision, workspace, workspace_bytes, range_flag, nullptr, nullptr, 0);
+}
+
+// (v108) FourierUnit.forward of layer l + 1 that also finishes the Winograd local conv of layer l (lama_winograd_conv3x3_fwd with
+// LAMA_CONV_DEFER_OUT): its output transform rides in the rfft2 launch (lama_rfft2_winograd_out_fwd) or, where no kernel does that, runs first
+extern "C" int lama_fourier_unit_winograd_out_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
+                                                  const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
+                                                  void* workspace, size_t workspace_bytes, uint32_t* range_flag,
+                                                  const lama_conv2d_args* wino_args, void* wino_workspace, size_t wino_workspace_bytes) {
+    if (!wino_args || !wino_workspace) return LAMA_ERR_BAD_ARG;
+    return fourier_unit_impl(stream, x, w_packed, bias, y, batch, add_input, precision, workspace, workspace_bytes, range_flag, wino_args,
+                             wino_workspace, wino_workspace_bytes);
 }
 

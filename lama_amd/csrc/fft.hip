@@ -582,14 +582,13 @@ __device__ __forceinline__ void ip_pass(float2* buf, const float2* tw, int Ns, i
 }
 
 template <bool TR = false, bool HF = false>
-__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
+__device__ __forceinline__ void rfft2_ip64_body(const FftParams& p, const int plane) {
     FFT_IO(p);
     if (p.prio) __builtin_amdgcn_s_setprio(3);
     constexpr int h = IP_N, w = IP_N, wf = IP_WF, hh = 32, wh = 32, RSW = IP_RSW;
     float2* tww = reinterpret_cast<float2*>(lama_smem);
     float2* P = tww + w;                       // h == w: one twiddle table
     const int tid = threadIdx.x;
-    const int plane = blockIdx.x;
     const int b = plane / p.C, c = plane - b * p.C;
     // 1. row pairs straight from HBM (requested before the twiddles are computed): P[f][n] = (x[2f][n], x[2f+1][n])
     float4 ra[2], rb[2];
@@ -669,6 +668,23 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) 
             fft_st4(dre + per_plane + i4 * 4, make_float4(im[0], im[1], im[2], im[3]));
         }
     }
+}
+
+template <bool TR = false, bool HF = false>
+__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_kernel(FftParams p) {
+    rfft2_ip64_body<TR, HF>(p, blockIdx.x);
+}
+
+// Round 4: rfft2 of layer l + 1 and the Winograd output transform of layer l in ONE launch.  Both are memory-bound and independent (the out
+// transform's result is first read by the Winograd GEMM / global launch of layer l + 1, both behind this launch), and every rfft2 workgroup has a
+// 5 us phase in LDS during which the chip's HBM is idle (all 1536 planes are resident and run load / transform / store in lock-step): the
+// out transform's streaming workgroups (no LDS use, two per CU next to the six FFT workgroups) fill it.  On two streams the pair takes 28.6
+// instead of 34.9 us (tools/overlap_probe.py); as one launch there is no cross-queue signal to pay.  Workgroups 0 .. nout - 1: out transform
+// (grid-stride), nout .. nout + planes - 1: one plane each.
+#include "wino_out_dev.inc"
+__global__ __launch_bounds__(LAMA_NTHREADS) void rfft2_ip64_wino_out_kernel(FftParams p, WoParams q, int nout) {
+    if ((int)blockIdx.x < nout) lama_wino_out_body(q, (long long)blockIdx.x * LAMA_NTHREADS + threadIdx.x, (long long)nout * LAMA_NTHREADS);
+    else rfft2_ip64_body<false, false>(p, (int)blockIdx.x - nout);
 }
 
 template <bool TR = false, bool HF = false>
@@ -1738,7 +1754,7 @@ extern "C" size_t lama_fft_workspace_bytes(int32_t batch, int32_t C, int32_t h, 
     } while (0)
 
 static int rfft2_impl(void* stream, const lama_tensor* x, const lama_tensor* spec, const lama_tensor* mask, int32_t batch,
-                      void* workspace, size_t workspace_bytes) {
+                      void* workspace, size_t workspace_bytes, const WoParams* wo = nullptr) {
     if (!fft_args_ok(x, spec, batch)) return LAMA_ERR_BAD_ARG;
     if (x->dtype != spec->dtype || (x->dtype != LAMA_DT_F32 && x->dtype != LAMA_DT_F16)) return LAMA_ERR_UNSUPPORTED;
     const bool hf = x->dtype == LAMA_DT_F16;
@@ -1768,7 +1784,15 @@ static int rfft2_impl(void* stream, const lama_tensor* x, const lama_tensor* spe
         const bool even = p.nplanes % p.ppw == 0;
         p.trace = hf ? nullptr : fft_trace_buf();
         p.prio = lama_side_prio();
-        if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && spec_al)
+        if (wo) {   // with the Winograd output transform of the layer before in the same launch: the one-buffer 64 x 64 kernel only
+            if (!(p.h == 64 && p.w == 64 && !hf && fft_inplace() && spec_al)) return LAMA_ERR_UNSUPPORTED;
+            p.trace = nullptr;
+            int nout = 512;                            // two streaming workgroups per CU next to the six FFT workgroups
+#ifdef LAMA_PROFILING
+            { static const int v = lama_env_int("LAMA_FFT_NOUT", 0); if (v > 0) nout = v; }
+#endif
+            hipLaunchKernelGGL(rfft2_ip64_wino_out_kernel, dim3(nout + p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), st, p, *wo, nout);
+        } else if (!p.trace && p.h == 64 && p.w == 64 && fft_inplace() && spec_al)
             FFT_GO(rfft2_ip64_kernel, (false), dim3(p.nplanes), blk, (size_t)(IP_N + IP_BUF) * sizeof(float2), p);
         else if (p.h == 128 && p.w == 128 && fft_inplace() && spec_al)
             FFT_GO(rfft2_ipn_kernel, (128), dim3(p.nplanes), blk, (size_t)(128 + 128 * 65) * sizeof(float2), p);
@@ -1786,6 +1810,7 @@ static int rfft2_impl(void* stream, const lama_tensor* x, const lama_tensor* spe
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
+    if (wo) return LAMA_ERR_UNSUPPORTED;
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
@@ -1929,4 +1954,15 @@ extern "C" int lama_irfft2_masked_fwd(void* stream, const lama_tensor* spec, con
                                       int32_t batch, void* workspace, size_t workspace_bytes) {
     if (!mask_y) return LAMA_ERR_BAD_ARG;
     return irfft2_impl(stream, spec, resid, mask_y, y, batch, workspace, workspace_bytes);
+}
+// (v108) rfft2 of one layer and the output transform of the Winograd local conv of the layer before (lama_winograd_conv3x3_fwd called with
+// LAMA_CONV_DEFER_OUT and the same `wino_args` / workspace) in ONE launch: both are memory-bound and independent, and the FFT workgroups leave
+// the HBM idle while they transform.  64 x 64 fp32 planes (the one-buffer kernel) only: LAMA_ERR_UNSUPPORTED otherwise, nothing launched --
+// the caller then runs lama_winograd_out_fwd + lama_rfft2_fwd.
+extern "C" int lama_rfft2_winograd_out_fwd(void* stream, const lama_tensor* x, const lama_tensor* spec, int32_t batch, void* workspace,
+                                           size_t workspace_bytes, const lama_conv2d_args* wino_args, void* wino_workspace, size_t wino_workspace_bytes) {
+    WoParams wo;
+    const int rc = lama_wino_out_params(wino_args, wino_workspace, wino_workspace_bytes, &wo);
+    if (rc) return rc;
+    return rfft2_impl(stream, x, spec, nullptr, batch, workspace, workspace_bytes, &wo);
 }

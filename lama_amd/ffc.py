@@ -184,13 +184,13 @@ class _Exec:
         flag = self._cur_flag if kw.get('precision') in (L.PREC_F16X3, L.PREC_F16) else None
         self.lib.conv2d(*a, range_flag=flag, **kw)
 
-    def fourier_unit(self, *a, precision: int = L.PREC_F32, stream: int = 0):
+    def fourier_unit(self, *a, precision: int = L.PREC_F32, stream: int = 0, wino_out=None):
         flag = self._cur_flag if precision in (L.PREC_F16X3, L.PREC_F16) else None
-        self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag)
+        self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag, wino_out=wino_out)
 
     def winograd_conv3x3(self, *a, precision: int = L.PREC_F16X3, **kw):
         flag = self._cur_flag if precision == L.PREC_F16X3 else None
-        self.lib.winograd_conv3x3(*a, precision=precision, range_flag=flag, **kw)
+        return self.lib.winograd_conv3x3(*a, precision=precision, range_flag=flag, **kw)
 
 
 _RANGE_MSG = ('an activation left the range of the fp16 split (|x| > 65504 or NaN) in this forward; '
@@ -278,9 +278,9 @@ class FourierUnit(_HipModule):
                             shift.contiguous())
         return self._packed
 
-    def run(self, x: L.Tensor4, y: L.Tensor4, batch: int, add_input: bool, ws: torch.Tensor, stream: int):
+    def run(self, x: L.Tensor4, y: L.Tensor4, batch: int, add_input: bool, ws: torch.Tensor, stream: int, wino_out=None):
         wp, shift = self._pack()
-        self._exec.fourier_unit(x, wp, shift, y, batch, add_input, ws, precision=self.precision, stream=stream)
+        self._exec.fourier_unit(x, wp, shift, y, batch, add_input, ws, precision=self.precision, stream=stream, wino_out=wino_out)
 
     def workspace(self, x: torch.Tensor) -> torch.Tensor:
         b, c, h, w = x.shape
@@ -323,13 +323,14 @@ class SpectralTransform(_HipModule):
         return self._packed
 
     def run_front(self, xg: L.Tensor4, x1: torch.Tensor, t: torch.Tensor, ws: torch.Tensor, batch: int, stream: int,
-                  x1_ready: bool = False):
+                  x1_ready: bool = False, wino_out=None):
         """x1 = relu(bn(conv1(xg))); t = x1 + fu(x1).  (conv2 is fused by the caller.)  ``x1_ready``: the producer of xg already
-        wrote x1 from its epilogue (fuse1_operands)."""
+        wrote x1 from its epilogue (fuse1_operands).  ``wino_out``: the deferred output transform of the previous layer's Winograd local
+        conv, finished inside this FourierUnit's first launch (round 4)."""
         pk = self._packed
         if not x1_ready:
             self._exec.conv2d(xg, pk['w1'], L.view(x1), batch, 1, bias=pk['b1'], act=L.ACT_RELU, precision=self.precision, stream=stream)
-        self.fu.run(L.view(x1), L.view(t), batch, True, ws, stream)
+        self.fu.run(L.view(x1), L.view(t), batch, True, ws, stream, wino_out=wino_out)
 
     def fuse1_operands(self, x1: torch.Tensor) -> Optional[tuple]:
         """(packed conv1 weights in the channel order of the producing kernel's accumulators, BatchNorm shift, x1 view) for the
@@ -485,8 +486,13 @@ class FFC(_HipModule):
             rl = None if resid is None else L.view(resid, 0, ocl)
             if wino:
                 try:
-                    ex.winograd_conv3x3(L.view(src), pk['w_lout_wino'], L.view(dst, 0, ocl), B, scratch['wino'], pk['b_l'], act, rl, precision=prec,
-                                        stream=stream)
+                    # one-stream plans (scratch['defer_out'], _build_plan): only the GEMM half now -- the output transform rides in the rfft2
+                    # launch of the NEXT layer (or is flushed by the plan), where it fills the HBM-idle transform phase of the FFT workgroups
+                    defer = bool(scratch.get('defer_out')) and side is None
+                    pend = ex.winograd_conv3x3(L.view(src), pk['w_lout_wino'], L.view(dst, 0, ocl), B, scratch['wino'], pk['b_l'], act, rl,
+                                               precision=prec, stream=stream, defer_out=defer)
+                    if defer:
+                        scratch['pending_out'] = (pend, scratch['wino'])
                     return
                 except LamaError as e:      # a view the Winograd entry does not take (alignment, 32-bit offsets of very tall planes): the direct kernel
                     if e.code != L.ERR_UNSUPPORTED:
@@ -515,7 +521,7 @@ class FFC(_HipModule):
                 spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, side.cuda_stream, x1_ready)
             main.wait_stream(side)                      # join: t is ready for the global conv
         else:
-            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready)
+            spec.run_front(L.view(src, cl, cg), scratch['x1'], scratch['t'], scratch['ws'], B, st, x1_ready, wino_out=scratch.pop('pending_out', None))
             local_conv(st, ex.cooperative_serial)
         # the global branch; by the time it runs this layer's own x1 has been consumed (rfft2 and the x + fu(x) add are upstream of t)
         fuse1 = None
@@ -925,6 +931,8 @@ class FFCResNetGenerator(_HipModule):
         self.inplace_residual = True
         self.alias_t = True
         self.alias_wino = True
+        # the Winograd output transform of a residual layer inside the rfft2 launch of the next one (one-stream plans)
+        self.defer_wino_out = True
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
@@ -1032,7 +1040,17 @@ class FFCResNetGenerator(_HipModule):
         if scratch and scratch.get('wino') is not None and not wino:
             scratch['wino'] = None                   # 33 MB at 8 x 64 x 64 that no launch would read
         serial = wino and self.serial_with_winograd
-        if serial and self.alias_wino:
+        if serial and self.defer_wino_out:
+            # the Winograd output transform of layer l rides in the rfft2 launch of layer l + 1 (FFC.launch): the partial sums P live until then,
+            # i.e. while that rfft2 writes the FIRST spectrum -- P goes behind it, over the second spectrum (written by the spectral GEMM, after
+            # that launch) and a tail: 211 + 7.5 MB touched per layer at 8 x 512^2
+            B_, C1, H_, W_ = scratch['x1'].shape
+            spec_elems = (((B_ * 2 * C1 * H_ * (W_ // 2 + 1) * 4) + 255) & ~255) // 4
+            wn = scratch['wino']
+            ws = torch.empty(max(scratch['ws'].numel(), spec_elems + wn.numel()), device=device, dtype=torch.float32)
+            scratch['ws'], scratch['wino'] = ws, ws[spec_elems:spec_elems + wn.numel()]
+            scratch['defer_out'] = True
+        elif serial and self.alias_wino:
             # one-stream order: the FourierUnit's spectra (rfft2 -> GEMM -> irfft2) are dead when the Winograd launches start and the
             # Winograd partial sums are dead when the next layer's rfft2 starts: one allocation for both (8 x 512^2: 33.5 of 52 MB shared)
             ws, wn = scratch['ws'], scratch['wino']
@@ -1052,6 +1070,8 @@ class FFCResNetGenerator(_HipModule):
 
         steps = plan['steps']
         x1_ready = False
+        if plan['scratch']:
+            plan['scratch'].pop('pending_out', None)        # (left behind by a run that raised)
         pipe = SidePipe(plan['side']) if (plan['side'] is not None and self.pipeline_local and x.is_cuda) else None
         for i, st in enumerate(steps):
             kind = st[0]
@@ -1065,8 +1085,12 @@ class FFCResNetGenerator(_HipModule):
                 nxt = steps[i + 1][1] if fuse and i + 1 < len(steps) and steps[i + 1][0] == 'res' else None
                 x1_ready = lay.run(B(s), B(t), B(d), plan['scratch'], side=pipe or plan['side'], x1_ready=x1_ready, next_block=nxt,
                                    fuse=fuse)
-                if pipe is not None and (i + 1 == len(steps) or steps[i + 1][0] != 'res'):
-                    pipe.join()                     # the last local conv: everything downstream reads its x_l
+                if i + 1 == len(steps) or steps[i + 1][0] != 'res':
+                    pend = plan['scratch'].pop('pending_out', None)
+                    if pend is not None:            # the last residual layer's output transform has no rfft2 launch to ride in
+                        self._exec.lib.winograd_out(pend[0], pend[1], self._exec.stream(x))
+                    if pipe is not None:
+                        pipe.join()                 # the last local conv: everything downstream reads its x_l
             elif kind == 'up':
                 _, lay, s, d, bn, act = st
                 lay.run(B(s), B(d), bn, act)

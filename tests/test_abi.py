@@ -41,6 +41,12 @@ def test_host_binding_covers_the_header():
     lib = LamaLib(B.build(verbose=False))
     for n in _declared():
         assert getattr(lib._l, n) is not None
+    # every entry point the binding CALLS has its argument types declared: an unset argtypes passes pointers as C ints (truncated to 32 bits --
+    # round 4: a launch with truncated pointers is a memory fault on the GPU box and nothing on the CPU emulator tests that never reach it)
+    src = open(os.path.join(ROOT, 'lama_amd', '_lib.py')).read()
+    called = set(re.findall(r'self\._l\.(lama_[a-z0-9_]+)\(', src))
+    untyped = sorted(n for n in called if getattr(lib._l, n).argtypes is None and n not in ('lama_version',))
+    assert not untyped, untyped
 
 
 def _gfx950_code_objects(path):

@@ -540,6 +540,26 @@ def test_winograd_conv3x3_emulated(case, prec):
     assert float((y - yd).abs().max()) < 2 * tol['atol']
     with pytest.raises(L.LamaError):                                         # workspace too small
         lib.winograd_conv3x3(L.view(xbuf, 1, cin), wp, L.view(ybuf, 2, cout), B, ws[:16], bias, case['act'], None, precision=prec)
+    if case['cin'] == 32 and cout == 128:
+        # round 4 (v108): the GEMM half alone (LAMA_CONV_DEFER_OUT), then the output transform on its own / inside an rfft2 launch -- the same bits
+        for fused in (False, True):
+            y2 = torch.full((B, cout + 3, H, W), 7.0)
+            ws.zero_()
+            pend = lib.winograd_conv3x3(L.view(xbuf, 1, cin), wp, L.view(y2, 2, cout), B, ws, bias, case['act'], None if resid is None else L.view(resid),
+                                        precision=prec, defer_out=True)
+            assert float(y2.min()) == 7.0 and pend is not None
+            if fused:
+                xf = torch.randn(1, 2, 64, 64, generator=g)
+                sp, sp0 = torch.zeros(1, 4, 64, 33), torch.zeros(1, 4, 64, 33)
+                lib.rfft2_wino_out(L.view(xf), L.view(sp), 1, None, pend, ws)
+                lib.rfft2(L.view(xf), L.view(sp0), 1, None)
+                assert torch.equal(sp, sp0)
+                with pytest.raises(L.LamaError) as ei:                       # 32 x 32 planes: no kernel does both
+                    lib.rfft2_wino_out(L.view(xf[:, :, :32, :32].contiguous()), L.view(torch.zeros(1, 4, 32, 17)), 1, None, pend, ws)
+                assert ei.value.code == L.ERR_UNSUPPORTED
+            else:
+                lib.winograd_out(pend, ws)
+            assert torch.equal(y2, ybuf)
     if case['cin'] <= 64 and cout == 128:
         # round 4: zero padding (the dgrad convs of the reverse pass): rows / columns outside the plane read as zeros, first / last band and column
         refz = _conv_ref(x, w, 1, 1, False, False, bias, case['act'], resid, scale=scale)
