@@ -137,7 +137,10 @@ class _FFCLayerTape:
         # local input
         done = False
         if 'wd_l_wino' in bw and sh.get('wino_b') is not None:
+            # the frame kernel FIRST: it has bounds of its own (channels % 64, its LDS footprint, batch <= 65535) and refuses with
+            # ERR_UNSUPPORTED before anything was launched -- then neither half of the pair runs and the direct conv + fold below takes the layer
             try:
+                lib.dgrad_ring(L.view(gm), bw['wr_l'], cl, sh['ring_l'], B, st)
                 lib.winograd_conv3x3(L.view(gm), bw['wd_l_wino'], L.view(sh['gi_l']), B, sh['wino_b'], None, L.ACT_NONE, None, precision=prec,
                                      stream=st, pad_mode=L.PAD_ZERO)
                 done = True
@@ -146,7 +149,6 @@ class _FFCLayerTape:
                     raise
                 sh['wino_b'] = None
         if done:
-            lib.dgrad_ring(L.view(gm), bw['wr_l'], cl, sh['ring_l'], B, st)
             lib.reflect_pad_bwd_fused(L.view(sh['gi_l']), None, v(identity, 0, cl), 1, v(mask, 0, cl), L.ACT_RELU, v(g_src, 0, cl),
                                       v(gm_src, 0, cl), B, st, ring=sh['ring_l'])
         else:

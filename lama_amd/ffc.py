@@ -121,7 +121,8 @@ class _Exec:
     def __init__(self, lib: Optional[L.LamaLib] = None):
         self._lib = lib
         self.injected = lib is not None
-        self._flags = {}
+        self._flags = {}                  # one flag per DEVICE of this exec -- shared by every generator that runs on it (the default exec: all of them)
+        self._deferred_since_read = {}    # device -> deferred scopes have run since the flag was last read
         self._depth = 0
         self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
@@ -146,12 +147,18 @@ class _Exec:
     def range_scope(self, t: torch.Tensor, precision: int, deferred: bool = False):
         """``deferred``: the outermost scope does NOT read the flag back (no host synchronisation: forwards can queue behind one another);
         the flag stays raised on the device -- the kernels only ever OR into it -- until ``check_range`` reads it at the caller's next
-        synchronisation point (FFCResNetGenerator.defer_range_check)."""
+        synchronisation point (FFCResNetGenerator.defer_range_check).  The flags belong to the exec (one per device), not to a generator: two
+        generators on the default exec share them, so ``check_range`` of either reports -- and clears -- what both have raised."""
         outer = self._depth == 0
         if outer and precision in (L.PREC_F16X3, L.PREC_F16):
-            key = str(t.device)
+            key = self._dev_key(t.device)
             if key not in self._flags:
                 self._flags[key] = torch.zeros(1, dtype=torch.int32, device=t.device)
+            elif not deferred and self._deferred_since_read.get(key):
+                # a flag left raised by DEFERRED forwards nobody asked about (check_range) is not this forward's: a self-checking forward starts
+                # from a clean flag (an asynchronous 4-byte memset on the launch stream -- no host synchronisation)
+                self._flags[key].zero_()
+            self._deferred_since_read[key] = bool(deferred)
             self._cur_flag = self._flags[key]
         self._depth += 1
         try:
@@ -172,13 +179,23 @@ class _Exec:
         """Read back AND clear (one 4-byte D2H per device = a host synchronisation with that device's current stream) the flag(s) that deferred
         scopes left on the device: True when a forward since the last read split an activation beyond 65504 (or a NaN)."""
         bad = False
+        want = None if device is None else self._dev_key(device)
         for key, flag in self._flags.items():
-            if device is not None and key != str(torch.device(device)):
+            if want is not None and key != want:
                 continue
+            self._deferred_since_read[key] = False
             if int(flag.item()) != 0:
                 flag.zero_()
                 bad = True
         return bad
+
+    @staticmethod
+    def _dev_key(device) -> str:
+        """'cuda' and 'cuda:<current>' are the same device: the flags are keyed by the indexed name (tensors always carry the index)."""
+        d = torch.device(device)
+        if d.type == 'cuda' and d.index is None:
+            d = torch.device('cuda', torch.cuda.current_device())
+        return str(d)
 
     def conv2d(self, *a, **kw):
         flag = self._cur_flag if kw.get('precision') in (L.PREC_F16X3, L.PREC_F16) else None
@@ -985,7 +1002,7 @@ class FFCResNetGenerator(_HipModule):
                 steps.append(('ffc', lay, cur, dst, pad_pending))
                 cur, cur_shape, pad_pending = dst, shp, 0
             elif isinstance(lay, FFCResnetBlock):
-                if scratch is None:
+                if 'rt' not in bufs:                   # first block: the scratch set of every SpectralTransform (None without a global branch)
                     scratch = lay.conv1.make_scratch(cur_shape, device, alias_t=self.alias_t)
                     new('rt', cur_shape)
                 # the block's output IN PLACE of its input (round 4): the second layer reads the input only as its residual operand, element
@@ -1086,7 +1103,8 @@ class FFCResNetGenerator(_HipModule):
                 x1_ready = lay.run(B(s), B(t), B(d), plan['scratch'], side=pipe or plan['side'], x1_ready=x1_ready, next_block=nxt,
                                    fuse=fuse)
                 if i + 1 == len(steps) or steps[i + 1][0] != 'res':
-                    pend = plan['scratch'].pop('pending_out', None)
+                    # (plan['scratch'] is None when the blocks have no global branch: resnet_conv_kwargs ratio_gin = ratio_gout = 0)
+                    pend = plan['scratch'].pop('pending_out', None) if plan['scratch'] else None
                     if pend is not None:            # the last residual layer's output transform has no rfft2 launch to ride in
                         self._exec.lib.winograd_out(pend[0], pend[1], self._exec.stream(x))
                     if pipe is not None:

@@ -217,7 +217,16 @@ def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, 
     rounds = plan_rounds(shapes, batch_size, world)
     lib = model.generator._exec.lib
     pool = ThreadPoolExecutor(io_threads)
+    try:
+        return _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext,
+                               device=device, rank=rank, world=world, dist=dist)
+    finally:
+        pool.shutdown()                      # on every exit path (a raise out of a bucket included): no worker thread outlives the call
+
+
+def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist) -> int:
     futures, written = [], 0
+    bucket_paths: List[str] = []             # the PNGs queued for the bucket whose range flag has not been read yet
 
     def submit_loads(rd):
         return [pool.submit(load_item, *items[i], pad_mod) for i in rd['batches'][rank]]
@@ -269,7 +278,8 @@ def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, 
                 mask_path = items[i][0]
                 h, w = sizes[i]
                 rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + out_ext      # bin/predict.py:69-72
-                futures.append(pool.submit(_write_png, os.path.join(outdir, rel), host[r * batch_size + j, :h, :w].copy()))
+                bucket_paths.append(os.path.join(outdir, rel))
+                futures.append(pool.submit(_write_png, bucket_paths[-1], host[r * batch_size + j, :h, :w].copy()))
                 written += 1
 
     pending = submit_loads(rounds[0]) if rounds else []
@@ -332,15 +342,26 @@ def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, 
                 return int(t.item()) != 0
             if world <= 1:
                 red = None
-            if not model.generator.check_range(u8.device, reduce=red):
+            # The PNG writes of this bucket are already queued (they overlap the compute); the flag is read only now.  Out-of-range forwards
+            # produced garbage images: with auto_fallback the restart overwrites every file, WITHOUT it check_range raises -- and the bucket's
+            # files are removed first, so that a LamaRangeError never leaves bad output on disk.
+            try:
+                in_range = model.generator.check_range(u8.device, reduce=red)
+            except L.LamaRangeError:
                 for f in futures:
                     f.result()
-                pool.shutdown()
+                for pth in bucket_paths:
+                    if os.path.exists(pth):
+                        os.remove(pth)
+                raise
+            if not in_range:
+                for f in futures:
+                    f.result()
                 raise _RangeRestart()
+            bucket_paths.clear()
             model.generator.drop_plan((batch_size, 4, Hp, Wp), u8.device)           # bucket done: free its buffers / graph
     for f in futures:
         f.result()
-    pool.shutdown()
     return written
 
 

@@ -130,3 +130,32 @@ def test_predict_overrides_are_typed_per_key():
         with pytest.raises(SystemExit):
             P.parse_overrides(['model.path=/m', 'indir=i', 'outdir=o', bad])
     assert set(P.KNOWN_KEYS) == P.STRING_KEYS | P.BOOL_KEYS | P.INT_KEYS | P.FLOAT_KEYS
+
+
+def test_predict_range_error_leaves_no_output_and_no_threads(tmp_path, monkeypatch):
+    """the range flag of a bucket is read after its PNG writes were queued.  Without auto_fallback check_range raises: the bucket's
+    (garbage) files must be gone again and the IO pool shut down; buckets that passed their own check keep their files."""
+    import threading
+    from lama_amd import _lib as L
+    indir, _ = _make_dataset(str(tmp_path))
+    outdir = str(tmp_path / 'out')
+    model, _, _ = _build_model()
+    items = P.list_dataset(indir, '.png')
+    gen = model.generator
+    gen.auto_fallback = False
+    calls = []
+    real = type(gen).check_range
+
+    def second_bucket_out_of_range(self, device=None, reduce=None):
+        calls.append(1)
+        if len(calls) == 2:                       # buckets are visited in sorted shape order: (32, 32) passes, (40, 56) "overflowed"
+            raise L.LamaRangeError('test: out of range')
+        return real(self, device, reduce)
+
+    monkeypatch.setattr(type(gen), 'check_range', second_bucket_out_of_range)
+    before = threading.active_count()
+    with pytest.raises(L.LamaRangeError):
+        P.predict(model, items, indir, outdir, pad_mod=8, batch_size=2, device='cpu', io_threads=2)
+    left = sorted(os.path.relpath(os.path.join(d, f), outdir) for d, _, fs in os.walk(outdir) for f in fs)
+    assert left == ['a/img1_mask000.png', 'img4_mask000.png'], left          # the two 32 x 32 images of the bucket that passed
+    assert threading.active_count() <= before and gen.defer_range_check is False

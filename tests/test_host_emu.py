@@ -339,3 +339,96 @@ def test_conv1_rides_in_the_global_branch_epilogue():
         assert st.fuse1_operands(torch.zeros(1, 192, 4, 5)) is None  # exact-fp32 path: never fused
     finally:
         ex.lib.conv2d = real
+
+
+def test_resnet_blocks_without_a_global_branch():
+    """resnet_conv_kwargs with ratio_gin = ratio_gout = 0 -- a layout the reference's constructor accepts (ffc.py:338-343:
+    every FFC of the blocks is local-only, ``x_g`` stays the int 0) -- has no SpectralTransform scratch set: the plan's end-of-blocks flush of
+    a deferred Winograd output transform must not touch it.  Fused plan (twice: cached plan), layer by layer, and the oracle agree."""
+    cfg = O.small_config(ngf=8, n_blocks=2)
+    cfg['resnet_conv_kwargs'] = dict(ratio_gin=0, ratio_gout=0, enable_lfu=False)
+    sd = O.make_synthetic_state_dict(cfg, seed=4, calib_hw=32)
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    res = gen.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    gen.set_exec(F._Exec(emu_lib()))
+    batch = O.make_synthetic_batch(1, 64, 64, seed=8)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        ref = O.generator_forward(x, sd, cfg)
+    y = gen(x)
+    assert float((y - ref).abs().max()) < 1e-4
+    assert torch.equal(gen(x), y)
+    plan = next(iter(gen._plans.values()))
+    assert plan['scratch'] is None
+    z = x
+    for layer in gen.model:
+        z = layer(z)
+    assert float((z - ref).abs().max()) < 1e-4
+
+
+def test_range_flag_device_key_and_stale_flag(monkeypatch):
+    """(i) ``check_range('cuda')`` must find the flag keyed 'cuda:<current index>' instead of returning True unread; (ii) a flag left
+    raised by deferred forwards nobody asked about is not charged to the next SELF-CHECKING forward of an in-range input."""
+    from lama_amd import _lib as L
+    monkeypatch.setattr(torch.cuda, 'current_device', lambda: 3)
+    assert F._Exec._dev_key('cuda') == 'cuda:3' and F._Exec._dev_key('cuda:1') == 'cuda:1' and F._Exec._dev_key(torch.device('cpu')) == 'cpu'
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = O.make_synthetic_state_dict(cfg, seed=5, calib_hw=32)
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen.set_exec(F._Exec(emu_lib()))
+    gen.auto_fallback = False
+    batch = O.make_synthetic_batch(1, 64, 64, seed=2)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    xb = x.clone()
+    xb[0, 1, 20:24, 30:34] = 3.0e5
+    gen.defer_range_check = True
+    gen(xb)                                                   # raises the flag on the device; nobody reads it
+    gen.defer_range_check = False
+    y = gen(x)                                                # self-checking forward of an in-range input: no LamaRangeError, no fallback
+    assert gen.precision == L.PREC_F16X3 and torch.isfinite(y).all()
+    assert gen.check_range('cpu') is True
+    with pytest.raises(L.LamaRangeError):
+        gen(xb)                                               # ... and it still catches its own
+
+
+def test_deferred_winograd_output_transform_plan_is_bit_identical():
+    """the host logic of the deferred Winograd output transform (pending_out hand-off in FFC.launch, the end-of-blocks flush, P placed
+    behind the first spectrum in _build_plan, the Winograd partial sums aliased onto the FourierUnit's dead spectra) on the EMULATOR.  The plan
+    of two residual blocks whose local conv is Winograd-eligible (160 = 128 | 32 channels, 16 x 32 planes: small enough to emulate) is run with
+    defer_wino_out / alias_wino on and off, and with the direct local conv: the same bits from the three Winograd plans, the oracle's values."""
+    cfg = O.small_config(ngf=40, n_blocks=2, n_downsampling=2)
+    cfg['resnet_conv_kwargs'] = dict(ratio_gin=0.2, ratio_gout=0.2, enable_lfu=False)
+    sd = O.make_synthetic_state_dict(cfg, seed=12, calib_hw=64)
+    first = 2 + cfg['n_downsampling']
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 160, 16, 32, generator=g).abs()
+    spec = dict(ratio_gin=0.2, ratio_gout=0.2)
+    with torch.no_grad():
+        rl, rg = x[:, :128], x[:, 128:]
+        for bi in range(cfg['n_blocks']):
+            rl, rg = O.ffc_resnet_block(rl, rg, sd, f'model.{first + bi}', spec)
+        ref = torch.cat([rl, rg], 1)
+    outs = {}
+    for name, (wino, defer, alias) in dict(defer=(True, True, True), plain=(True, False, False), direct=(False, False, False)).items():
+        gen = make_generator(None, kind='ffc_resnet', **cfg)
+        gen.load_state_dict(sd, strict=True)
+        ex = F._Exec(emu_lib())
+        ex.winograd = wino
+        gen.set_exec(ex)
+        gen.model = F.LayerSequence(*list(gen.model)[first:first + cfg['n_blocks']])      # the blocks' plan alone: 'in' is the (x_l | x_g) state
+        gen.defer_wino_out, gen.alias_wino = defer, alias
+        y = gen(x).clone()
+        if defer:
+            assert torch.equal(gen(x), y), name                   # the cached plan again (dirty buffers, P over the second spectrum)
+        plan = next(iter(gen._plans.values()))
+        sc = plan['scratch']
+        assert (sc.get('wino') is not None) == wino and bool(sc.get('defer_out')) == defer and 'pending_out' not in sc, name
+        if wino:
+            lo, hi = sc['ws'].data_ptr(), sc['ws'].data_ptr() + sc['ws'].numel() * 4
+            assert (lo <= sc['wino'].data_ptr() < hi) == (defer or alias), name
+        outs[name] = y
+    assert torch.equal(outs['defer'], outs['plain'])
+    scale = float(ref.abs().max())
+    assert float((outs['defer'] - ref).abs().max()) < 1e-4 * scale and float((outs['direct'] - ref).abs().max()) < 1e-4 * scale
