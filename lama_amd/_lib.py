@@ -74,7 +74,7 @@ class LamaLib:
         """``host_emulated``: the library is the x86 build of the kernel sources (tests/hipemu) and takes HOST pointers; the
         real library takes device pointers only and every wrapper below refuses CPU tensors."""
         self.host_emulated = host_emulated
-        path = path or os.environ.get('LAMA_HIP_LIB') or _DEFAULT     # LAMA_HIP_LIB: A/B-testing another build of the same ABI
+        path = path or _DEFAULT                   # (no environment variable chooses the library: tools pass a path -- use_library())
         if not os.path.exists(path):
             raise LamaError(f'{path} not found: build it with `python -m lama_amd.build` '
                             f'(hipcc --offload-arch=gfx950); lama_amd has no fallback path')
@@ -438,4 +438,16 @@ def get_lib() -> LamaLib:
     global _LIB
     if _LIB is None:
         _LIB = LamaLib()
+    return _LIB
+
+
+def use_library(path: str) -> LamaLib:
+    """Measurement tools only (tools/, bench.py --lib): make another build of the same ABI -- the profiling build, an A/B base -- the
+    process-wide library.  Must be called before anything loaded the default one; the product never calls it and no environment variable
+    selects a library."""
+    global _LIB
+    if _LIB is not None and os.path.abspath(_LIB.path) != os.path.abspath(path):
+        raise LamaError(f'use_library({path}): {_LIB.path} is already loaded')
+    if _LIB is None:
+        _LIB = LamaLib(path)
     return _LIB

@@ -18,19 +18,19 @@ CSRC = os.path.join(PKG, 'csrc')
 LIBDIR = os.path.join(PKG, 'lib')
 LIB = os.path.join(LIBDIR, 'liblama_hip.so')
 # Same sources with -DLAMA_PROFILING: kernel-selection overrides, timing ablations and timeline tracers read from the environment.
-# Only tools/ and the forced-path GPU tests load it (LAMA_HIP_LIB / LamaLib(path)); the product never does.
+# Only tools/ and the forced-path GPU tests load it (tools/_toollib.py, bench.py --lib, LamaLib(path)); the product never does.
 LIB_PROF = os.path.join(LIBDIR, 'liblama_hip_prof.so')
 SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'conv_f16.hip', 'fft.hip', 'elementwise.hip', 'refine.hip', 'metrics.hip']
 HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'gemm_wk_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'), os.path.join(CSRC, 'wino_dev.inc'), os.path.join(CSRC, 'convt_dev.inc'),
            os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
 # Every translation unit is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
-# Measured on MI355X / ROCm 7.2 (tools/race_probe8.py, race_probe9.py; probes 1-7 in the git history): a v_pk_*_f32 with an op_sel half-swizzle returns wrong
+# Measured on MI355X / ROCm 7.2 (the probes -- tools/race_probe1-9.py, overlap_stress.py -- are in the git history): a v_pk_*_f32 with an op_sel half-swizzle returns wrong
 # results while a wave of ANOTHER kernel executes MFMA instructions on the same SIMD (an inline-asm probe of that one instruction
 # fails 60 / 60 next to a bare MFMA loop, the plain forms pass).  hipcc's SLP vectoriser emits thousands of them for the float2
 # butterflies of the FFT kernels, which therefore produced wrong planes in up to 99 % of the runs next to a convolution on a second
 # stream -- and 0 of 100 000 without them.  Costs nothing measurable (bench: 555 vs 559 images/s, inside the run-to-run noise).
 NO_PACKED_FP32 = ['-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
-PROF_ONLY_SOURCES = ['debug_probes.hip']      # the probes of tools/race_probe8/9.py: built WITH packed fp32, on purpose
+PROF_ONLY_SOURCES = ['debug_probes.hip']      # lama_debug_mfma_peak (bench.py peak_sustained) + the opcode probes of the co-residency investigation: built WITH packed fp32, on purpose
 PER_SOURCE_FLAGS = {}                        # filled below: NO_PACKED_FP32 for every product source
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc',
                '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC]

@@ -179,6 +179,140 @@ def _write_png(path: str, rgb: np.ndarray):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# one step fed from host memory
+# ----------------------------------------------------------------------------------------------------------------
+
+class HostFedStep:
+    """One predict step -- mask binarisation (bin/predict.py:84), mask-compose + generator + blend (trainers/default.py:56-71), u8 HWC
+    quantisation (bin/predict.py:92) -- fed from / drained to pinned HOST buffers, double-buffered, as ONE hipGraph launch per step:
+
+        launch(p):   H2D  host input set 1-p -> device set 1-p        (the NEXT batch)
+                  || compute on device set p -> u8[p]                 (THIS batch)
+                  || D2H  u8[1-p] -> host result set 1-p              (the PREVIOUS batch; ``drain``)
+
+    The three are parallel branches INSIDE the captured graph.  Round 4 measured that on ROCm 7.2 a graph replay does not run beside copies
+    issued on other streams (bench.py: 788 images/s around the replay, 819 with plain launches, 825 with resident inputs): as nodes of the
+    same graph the copies overlap the kernels and the ~270 launches of a forward still cost one hipGraphLaunch.  The caller alternates
+    p = 0, 1, 0, ...: it fills host set 1-p before ``launch(p)`` (after ``wait`` has told it that the launch that last read that set is
+    complete), calls ``prime(p0)`` once before the first launch and ``flush(p_last)`` after the last.  ``drain=False`` (multi-rank: the results go
+    through the gather instead) leaves the D2H branch out.  On a CPU device (the emulator tests) the same body runs eagerly, unpinned."""
+
+    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True):
+        self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == 'cuda'
+        self.drain, self.binarize = drain, binarize
+        pin = dict(pin_memory=True) if self.on_gpu else {}
+        self.h_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
+        self.h_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
+        self.h_u8 = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, **pin) for _ in range(2)] if drain else None
+        self.d_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.d_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.u8 = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.graphs = [None, None]
+        self.done = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
+        self._launched = [False, False]
+        if self.on_gpu:
+            self.s_in, self.s_out = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+
+    # -- host views -----------------------------------------------------------------------------------------------
+    def host(self, p: int):
+        return self.h_img[p].numpy(), self.h_mask[p].numpy()
+
+    def result(self, p: int) -> np.ndarray:
+        return self.h_u8[p].numpy()
+
+    # -- pieces ---------------------------------------------------------------------------------------------------
+    def _compute(self, p: int):
+        lib = self.model.generator._exec.lib
+        mask = self.d_mask[p]
+        batch = dict(image=self.d_img[p], mask=(mask > 0) * 1 if self.binarize else mask)          # bin/predict.py:84
+        keep = self.model.keep_predicted_image
+        self.model.keep_predicted_image = False
+        try:
+            with torch.no_grad():
+                out = self.model(batch)['inpainted']                                             # bin/predict.py:85
+        finally:
+            self.model.keep_predicted_image = keep
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else 0
+        lib.quantize_u8_hwc(L.view(out), self.u8[p], self.n, self.Hp, self.Wp, stream)             # bin/predict.py:92 on the device
+
+    def _body(self, p: int):
+        q = 1 - p
+        if not self.on_gpu:
+            self.d_img[q].copy_(self.h_img[q]); self.d_mask[q].copy_(self.h_mask[q])
+            if self.drain:
+                self.h_u8[q].copy_(self.u8[q])
+            self._compute(p)
+            return
+        main = torch.cuda.current_stream(self.device)
+        self.s_in.wait_stream(main)
+        with torch.cuda.stream(self.s_in):
+            self.d_img[q].copy_(self.h_img[q], non_blocking=True)
+            self.d_mask[q].copy_(self.h_mask[q], non_blocking=True)
+        if self.drain:
+            self.s_out.wait_stream(main)
+            with torch.cuda.stream(self.s_out):
+                self.h_u8[q].copy_(self.u8[q], non_blocking=True)
+        self._compute(p)
+        main.wait_stream(self.s_in)
+        if self.drain:
+            main.wait_stream(self.s_out)
+
+    def _capture(self, p: int):
+        gen = self.model.generator
+        keep = (gen.use_graph, gen.defer_range_check)
+        gen.use_graph, gen.defer_range_check = False, True       # the plan's launches go into THIS graph; no flag read-back (a host sync) inside it
+        try:
+            if self.graphs[1 - p] is None:                       # first capture: pack the weights / build the plan outside it
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    self._compute(p)
+                torch.cuda.current_stream(self.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog thread polls events of the gather that may still be in flight on the side stream
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._body(p)
+            self.graphs[p] = g
+        finally:
+            gen.use_graph, gen.defer_range_check = keep
+
+    # -- the caller's four verbs ----------------------------------------------------------------------------------
+    def prime(self, p: int):
+        """H2D of host set p on the current stream (before the first launch of a run)."""
+        self.d_img[p].copy_(self.h_img[p], non_blocking=self.on_gpu)
+        self.d_mask[p].copy_(self.h_mask[p], non_blocking=self.on_gpu)
+
+    def launch(self, p: int):
+        if not self.on_gpu:
+            gen = self.model.generator
+            keep, gen.defer_range_check = gen.defer_range_check, True
+            try:
+                self._body(p)
+            finally:
+                gen.defer_range_check = keep
+            return
+        if self.graphs[p] is None:
+            self._capture(p)
+        self.graphs[p].replay()
+        self.done[p].record(torch.cuda.current_stream(self.device))
+        self._launched[p] = True
+
+    def wait(self, p: int):
+        """Host: until the most recent launch(p) is complete (its H2D has read host set 1-p, its D2H has filled result(1-p))."""
+        if self.on_gpu and self._launched[p]:
+            self.done[p].synchronize()
+
+    def flush(self, p: int):
+        """D2H of u8[p] (the last launch's own result: nothing follows to carry it) and a host wait for it."""
+        if self.drain:
+            self.h_u8[p].copy_(self.u8[p], non_blocking=self.on_gpu)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # the predict loop
 # ----------------------------------------------------------------------------------------------------------------
 
@@ -225,54 +359,24 @@ def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, 
 
 
 def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist) -> int:
+    """The rounds of one attempt.  Per bucket (padded shape) a ``HostFedStep``: round k computes from device input set k & 1 while the SAME graph
+    launch uploads round k + 1's decoded images into the other set and (one rank) downloads round k - 1's u8 results; the host fills the
+    pinned set of round k + 1 and queues round k - 2's PNG writes while round k runs.  Several ranks: the results go through the one
+    collective -- ``gather_to_root`` of the u8 batch, on a side stream behind the step -- and rank 0 downloads the gathered rounds."""
     futures, written = [], 0
     bucket_paths: List[str] = []             # the PNGs queued for the bucket whose range flag has not been read yet
-
-    def submit_loads(rd):
-        return [pool.submit(load_item, *items[i], pad_mod) for i in rd['batches'][rank]]
-
-    # host staging: one PINNED image / mask / result buffer per bucket shape (a pageable 58 MB batch copies at a fraction of the
-    # PCIe rate and blocks the launch thread: ~5 ms against a 12 ms step), filled in place by the decoded items
     on_gpu = torch.device(device).type == 'cuda'
-    staging: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+    side = torch.cuda.Stream(device=device) if on_gpu else None     # gather + D2H of the gathered rounds, beside the next round's compute
 
-    def staging_of(Hp, Wp):
-        if (Hp, Wp) not in staging:
-            staging.clear()                     # buckets are visited one after the other: keep one shape's buffers
-            staging[(Hp, Wp)] = (torch.zeros(batch_size, 3, Hp, Wp, dtype=torch.float32, pin_memory=on_gpu),
-                                 torch.zeros(batch_size, 1, Hp, Wp, dtype=torch.float32, pin_memory=on_gpu),
-                                 torch.zeros(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, pin_memory=on_gpu) if rank == 0 else None)
-        return staging[(Hp, Wp)]
+    loads: Dict[int, list] = {}
 
-    # the pinned staging buffers are refilled in place every round: the H2D copies of round r must have run before the host writes
-    # round r + 1 into them (only rank 0 synchronises its stream for the D2H; the other ranks would race), and a bucket's plan /
-    # buffers must not be released while the round that uses them is still in flight
-    h2d_done = torch.cuda.Event() if on_gpu else None
-    h2d_pending = False
+    def submit_loads(r):
+        if r < len(rounds) and r not in loads:
+            loads[r] = [pool.submit(load_item, *items[i], pad_mod) for i in rounds[r]['batches'][rank]]
 
-    side = torch.cuda.Stream(device=device) if on_gpu else None     # gather + D2H of the results, beside the next round's compute
-    prev = None
-
-    def drain(rd, u8, gathered, work, h_out, done):
-        """Rank 0: wait for ONE round's gathered images (not for whatever the compute stream is doing by now), queue the PNG writes."""
+    def write_round(rd, host):
+        """Rank 0: queue the PNG writes of one round from its u8 results on the host (``host`` = [ranks * batch_size, Hp, Wp, 3])."""
         nonlocal written
-        if on_gpu:
-            with torch.cuda.stream(side):
-                if work is not None:
-                    work.wait()                                 # the side stream waits for RCCL's stream
-                else:
-                    side.wait_event(done)                       # this round's quantize kernel
-                if rank == 0:
-                    h_out.copy_(gathered, non_blocking=True)    # D2H into the pinned result buffer
-            side.synchronize()
-        else:
-            if work is not None:
-                work.wait()
-            if rank == 0:
-                h_out.copy_(gathered)
-        if rank != 0:
-            return
-        host = h_out.numpy()
         for r, idxs in enumerate(rd['batches']):
             for j, i in enumerate(idxs):
                 mask_path = items[i][0]
@@ -282,84 +386,110 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
                 futures.append(pool.submit(_write_png, bucket_paths[-1], host[r * batch_size + j, :h, :w].copy()))
                 written += 1
 
-    pending = submit_loads(rounds[0]) if rounds else []
-    for ri, rd in enumerate(rounds):
-        Hp, Wp = rd['shape']
-        mine = rd['batches'][rank]
-        loaded = [f.result() for f in pending]
-        pending = submit_loads(rounds[ri + 1]) if ri + 1 < len(rounds) else []          # decode the next round under this one
-        u8 = torch.zeros(batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device)
-        h_img, h_mask, h_out = staging_of(Hp, Wp)
-        if mine:
-            if h2d_pending:
-                h2d_done.synchronize()
-                h2d_pending = False
-            img_np, mask_np = h_img.numpy(), h_mask.numpy()
+    submit_loads(0)
+    submit_loads(1)
+    r0 = 0
+    while r0 < len(rounds):
+        Hp, Wp = rounds[r0]['shape']
+        r1 = r0
+        while r1 < len(rounds) and rounds[r1]['shape'] == (Hp, Wp):
+            r1 += 1
+        K = r1 - r0
+        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1))
+        gathered = h_out = None
+        if world > 1 and rank == 0:
+            gathered = [torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device) for _ in range(2)]
+            h_out = [torch.zeros(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, **(dict(pin_memory=True) if on_gpu else {})) for _ in range(2)]
+        works = [None, None]
+        collected = [torch.cuda.Event() for _ in range(2)] if (on_gpu and world > 1) else None
+
+        def fill(pp, r):
+            img_np, mask_np = hs.host(pp)
+            loaded = [f.result() for f in loads.pop(r)]
             for j, x in enumerate(loaded):
                 img_np[j], mask_np[j] = x[0], x[1]
-            img_np[len(loaded):] = 0.0                                                # partial batch: zero padding
+            img_np[len(loaded):] = 0.0                                                # partial (or, for a rank without a batch, empty) round: zero padding
             mask_np[len(loaded):] = 0.0
-            image = h_img.to(device, non_blocking=True)
-            mask = h_mask.to(device, non_blocking=True)
-            if on_gpu:
-                h2d_done.record(torch.cuda.current_stream(image.device))
-                h2d_pending = True
-            batch = dict(image=image, mask=(mask > 0) * 1)                          # bin/predict.py:84
-            with torch.no_grad():
-                out = model(batch)['inpainted']                                    # bin/predict.py:85, out_key
-            stream = torch.cuda.current_stream(out.device).cuda_stream if out.is_cuda else 0
-            lib.quantize_u8_hwc(L.view(out), u8, len(mine), Hp, Wp, stream)        # bin/predict.py:92 on the device
-        # the only collective: the u8 output images.  Asynchronous, off the compute stream: round r's gather and its D2H run while
-        # round r + 1 is decoded, staged and launched; the host drains round r AFTER it has launched round r + 1
-        work = done = None
-        if on_gpu:
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(u8.device))
-        if world > 1:
-            gathered = torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device) if rank == 0 else None
+
+        def collect(pp):
+            """Several ranks: the round that launch(pp) just computed goes through the gather (side stream, behind the step); rank 0 downloads it."""
             if on_gpu:
                 with torch.cuda.stream(side):
-                    side.wait_event(done)
-                    work = gather_to_root(dist, gathered, u8, rank, world)
+                    side.wait_event(hs.done[pp])
+                    works[pp] = gather_to_root(dist, gathered[pp] if rank == 0 else None, hs.u8[pp], rank, world)
+                    works[pp].wait()                                                  # the side stream waits for RCCL's stream
+                    if rank == 0:
+                        h_out[pp].copy_(gathered[pp], non_blocking=True)
+                    collected[pp].record(side)
             else:
-                work = gather_to_root(dist, gathered, u8, rank, world)
-        else:
-            gathered = u8
-        last_of_bucket = ri + 1 == len(rounds) or rounds[ri + 1]['shape'] != rd['shape']
-        if prev is not None:
-            drain(*prev)
-        prev = (rd, u8, gathered, work, h_out, done)
-        if last_of_bucket:
-            drain(*prev)
-            prev = None
+                works[pp] = gather_to_root(dist, gathered[pp] if rank == 0 else None, hs.u8[pp], rank, world)
+                works[pp].wait()
+                if rank == 0:
+                    h_out[pp].copy_(gathered[pp])
+
+        fill(0, r0)
+        submit_loads(r0 + 2)
+        hs.prime(0)
+        for k in range(K):
+            pp = k & 1
+            if k + 1 < K:
+                fill(1 - pp, r0 + k + 1)          # (the launch that last read this host set -- step k - 2 -- is complete: waited for below, at k - 1)
+            submit_loads(r0 + k + 2)
+            submit_loads(r0 + k + 3)
+            if on_gpu and works[pp] is not None:
+                torch.cuda.current_stream(hs.device).wait_event(collected[pp])        # step k - 2's gather has read u8[pp]
+            hs.launch(pp)
+            if world > 1:
+                collect(pp)
+                if k >= 1:                        # round k - 1: gathered and downloaded while step k runs
+                    if on_gpu:
+                        collected[1 - pp].synchronize()
+                    if rank == 0:
+                        write_round(rounds[r0 + k - 1], h_out[1 - pp].numpy())
+            elif k >= 1:
+                hs.wait(1 - pp)                   # step k - 1 is complete: it downloaded round k - 2 and read the host set filled above
+                if k >= 2:
+                    write_round(rounds[r0 + k - 2], hs.result(pp))
+        pl = (K - 1) & 1
+        if world > 1:
             if on_gpu:
-                torch.cuda.current_stream(u8.device).synchronize()                  # every rank: the graph / buffers below are in flight
-                h2d_pending = False
-            # the bucket's ONE read-back of the fp16 split's range flag (the forwards above did not synchronise); all ranks decide alike
-            def red(bad, _dev=u8.device):
-                t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=_dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                return int(t.item()) != 0
-            if world <= 1:
-                red = None
-            # The PNG writes of this bucket are already queued (they overlap the compute); the flag is read only now.  Out-of-range forwards
-            # produced garbage images: with auto_fallback the restart overwrites every file, WITHOUT it check_range raises -- and the bucket's
-            # files are removed first, so that a LamaRangeError never leaves bad output on disk.
-            try:
-                in_range = model.generator.check_range(u8.device, reduce=red)
-            except L.LamaRangeError:
-                for f in futures:
-                    f.result()
-                for pth in bucket_paths:
-                    if os.path.exists(pth):
-                        os.remove(pth)
-                raise
-            if not in_range:
-                for f in futures:
-                    f.result()
-                raise _RangeRestart()
-            bucket_paths.clear()
-            model.generator.drop_plan((batch_size, 4, Hp, Wp), u8.device)           # bucket done: free its buffers / graph
+                collected[pl].synchronize()
+            if rank == 0:
+                write_round(rounds[r1 - 1], h_out[pl].numpy())
+        else:
+            hs.wait(pl)
+            if K >= 2:
+                write_round(rounds[r1 - 2], hs.result(1 - pl))
+            hs.flush(pl)
+            write_round(rounds[r1 - 1], hs.result(pl))
+        if on_gpu:
+            torch.cuda.current_stream(hs.device).synchronize()                      # every rank: the graphs / buffers below are idle now
+
+        # the bucket's ONE read-back of the fp16 split's range flag (the forwards above did not synchronise); all ranks decide alike
+        def red(bad, _dev=hs.device):
+            t = torch.tensor([1 if bad else 0], dtype=torch.int32, device=_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return int(t.item()) != 0
+        # The PNG writes of this bucket are already queued (they overlap the compute); the flag is read only now.  Out-of-range forwards
+        # produced garbage images: with auto_fallback the restart overwrites every file, WITHOUT it check_range raises -- and the bucket's
+        # files are removed first, so that a LamaRangeError never leaves bad output on disk (ADVICE r4).
+        try:
+            in_range = model.generator.check_range(hs.device, reduce=red if world > 1 else None)
+        except L.LamaRangeError:
+            for f in futures:
+                f.result()
+            for pth in bucket_paths:
+                if os.path.exists(pth):
+                    os.remove(pth)
+            raise
+        if not in_range:
+            for f in futures:
+                f.result()
+            raise _RangeRestart()
+        bucket_paths.clear()
+        model.generator.drop_plan((batch_size, 4, Hp, Wp), hs.device)               # bucket done: free its buffers / graphs
+        del hs, gathered, h_out
+        r0 = r1
     for f in futures:
         f.result()
     return written

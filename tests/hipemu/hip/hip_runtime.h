@@ -263,44 +263,6 @@ static inline hipemu_f32x16 hipemu_mfma_f32_32x32x16_f16(V8 a, V8 b, hipemu_f32x
     }
     return c;
 }
-// fp8 e4m3 (OCP "fn": bias 7, no infinities, 0x7f / 0xff = NaN)
-static inline float hipemu_e4m3_to_f32(uint8_t v) {
-    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
-    if (e == 15 && m == 7) return NAN;
-    const float x = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + m / 8.0f, e - 7);
-    return s ? -x : x;
-}
-// v_mfma_scale_f32_32x32x64_f8f6f4 with e4m3 operands (cbsz = blgp = 0): lane l holds row / column l % 32 and the K values 32 (l / 32) + (0..31) as 32
-// bytes; the e8m0 scale byte of a lane (opsel picks the byte of its scale register) applies to that lane's 32 values: term = a b 2^(sa - 127) 2^(sb - 127).
-// Operand positions and the scale were verified on an MI355X against a host reference (tools/ubench/mfma_fp8_mix.hip, profiles/r03s3_mfma_fp8_mix.txt);
-// the hardware sums its 64 products with ~14-15 bits (5e-5 relative), this emulation exactly.  Groundwork for DESIGN.md 9 item 8 (no kernel uses it yet).
-template <class V8I>
-static inline hipemu_f32x16 hipemu_mfma_scale_f32_32x32x64_f8(V8I a, V8I b, hipemu_f32x16 c, int cbsz, int blgp, int opsel_a, int scale_a, int opsel_b, int scale_b) {
-    if (cbsz != 0 || blgp != 0) { std::fprintf(stderr, "hipemu: only e4m3 operands of v_mfma_scale_f32_32x32x64_f8f6f4 are emulated\n"); std::abort(); }
-    static_assert(sizeof(V8I) == 32, "eight dwords per operand");
-    uint32_t mine[16], sc[2];
-    memcpy(&mine[0], &a, 32);
-    memcpy(&mine[8], &b, 32);
-    auto all = hipemu::exchange(mine, 16);
-    sc[0] = ((uint32_t)scale_a >> (8 * (opsel_a & 3))) & 0xffu;
-    sc[1] = ((uint32_t)scale_b >> (8 * (opsel_b & 3))) & 0xffu;
-    auto alls = hipemu::exchange(sc, 2);            // (the other deposit buffer: `all` stays valid)
-    const int l = hipemu::lane(), col = l & 31;
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        double acc = 0.0;
-        for (int kg = 0; kg < 2; ++kg) {
-            const uint8_t* ap = reinterpret_cast<const uint8_t*>(&all[row + 32 * kg][0]);
-            const uint8_t* bp = reinterpret_cast<const uint8_t*>(&all[col + 32 * kg][8]);
-            double part = 0.0;
-            for (int e = 0; e < 32; ++e) part += (double)hipemu_e4m3_to_f32(ap[e]) * (double)hipemu_e4m3_to_f32(bp[e]);
-            acc += ldexp(part, (int)alls[row + 32 * kg][0] - 127 + (int)alls[col + 32 * kg][1] - 127);
-        }
-        c[r] = (float)((double)c[r] + acc);
-    }
-    return c;
-}
-#define __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, cbsz, blgp, osa, sa, osb, sb) hipemu_mfma_scale_f32_32x32x64_f8(a, b, c, cbsz, blgp, osa, sa, osb, sb)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma_f32_32x32x16_f16(a, b, c)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu_mfma_f32_32x32x2f32(a, b, c)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32_16x16x4f32(a, b, c)

@@ -159,3 +159,59 @@ def test_predict_range_error_leaves_no_output_and_no_threads(tmp_path, monkeypat
     left = sorted(os.path.relpath(os.path.join(d, f), outdir) for d, _, fs in os.walk(outdir) for f in fs)
     assert left == ['a/img1_mask000.png', 'img4_mask000.png'], left          # the two 32 x 32 images of the bucket that passed
     assert threading.active_count() <= before and gen.defer_range_check is False
+
+
+def _bench_worker(rank, world, port, q):
+    import torch.distributed as dist
+    import bench
+    from lama_amd import _lib as L
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model, _, _ = _build_model()
+    lib = model.generator._exec.lib
+    B, R = 2, 32
+
+    def inputs(r):
+        return bench.synthetic_batch('cpu', 1234 + r, batch=B, res=R)
+
+    img, mask = inputs(rank)
+    loop = bench.StepLoop(model, lib, 'cpu', img, mask, dist=dist, rank=rank, world=world)
+    dt, range_ok = bench.timed_region(loop, steps=3, warmup=2)
+    assert range_ok and dt > 0 and loop.gathers == 5 and all(w is None or w.is_completed() for w in loop.gather_work)
+    assert bench.ranks_seen(dist, world, world) == world
+    try:
+        bench.ranks_seen(dist, world, world + 1)
+        raise RuntimeError('ranks_seen accepted a wrong --gpus')
+    except AssertionError:
+        pass
+    # every rank's MAX-reduced time is the same number
+    ts = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(ts, torch.tensor([dt], dtype=torch.float64))
+    assert all(float(t) == dt for t in ts)
+    if rank == 0:
+        # the writer rank holds every rank's u8 images in BOTH ring slots (the inputs do not change from step to step)
+        for r in range(world):
+            im, mk = inputs(r)
+            out = model(dict(image=im, mask=mk))['inpainted']
+            u8 = torch.empty(B, R, R, 3, dtype=torch.uint8)
+            lib.quantize_u8_hwc(L.view(out), u8, B, R, R, 0)
+            for k in range(2):
+                assert torch.equal(loop.gathered[k][r * B:(r + 1) * B], u8), (r, k)
+        q.put('ok')
+    else:
+        assert loop.gathered == [None, None]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_step_loop_world2_gloo():
+    """VERDICT r4 Next #8: bench.py's own step loop (double-buffered gather ring to the writer rank, closing barrier, MAX-reduced time,
+    n_ranks_seen assertion) on two gloo ranks with the emulated kernels -- so that the first real 8-GPU run is not the first execution of that
+    code with N > 1."""
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_bench_worker, args=(2, port, q), nprocs=2, join=True)
+    assert q.get() == 'ok'

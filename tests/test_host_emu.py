@@ -432,3 +432,47 @@ def test_deferred_winograd_output_transform_plan_is_bit_identical():
     assert torch.equal(outs['defer'], outs['plain'])
     scale = float(ref.abs().max())
     assert float((outs['defer'] - ref).abs().max()) < 1e-4 * scale and float((outs['direct'] - ref).abs().max()) < 1e-4 * scale
+
+
+def test_host_fed_step_double_buffering():
+    """lama_amd.predict.HostFedStep on the emulator (eager body, no graphs): five steps with DIFFERENT host inputs per step -- upload of batch
+    k + 1, compute of batch k, download of batch k - 1 per launch -- deliver, in order, the u8 images of the plain model on each batch."""
+    from lama_amd import _lib as L
+    from lama_amd.predict import HostFedStep
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = {'generator.' + k: v for k, v in O.make_synthetic_state_dict(cfg, seed=11, calib_hw=32).items()}
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
+    model.load_state_dict(sd, strict=True)
+    model.freeze()
+    model.generator.set_exec(F._Exec(emu_lib()))
+    lib = model.generator._exec.lib
+    n, H, W, steps = 1, 32, 40, 4
+    batches = [O.make_synthetic_batch(n, H, W, seed=30 + k) for k in range(steps)]
+    want = []
+    for b in batches:
+        out = model(dict(image=b['image'].clone(), mask=(b['mask'] * 0.5 > 0) * 1))['inpainted']
+        u8 = torch.empty(n, H, W, 3, dtype=torch.uint8)
+        lib.quantize_u8_hwc(L.view(out), u8, n, H, W, 0)
+        want.append(u8)
+    hs = HostFedStep(model, n, H, W, 'cpu', drain=True)
+
+    def fill(p, k):
+        im, mk = hs.host(p)
+        im[:] = batches[k]['image'].numpy()
+        mk[:] = batches[k]['mask'].numpy() * 0.5           # a gray mask: any non-zero value is "hole" (bin/predict.py:84)
+
+    got = {}
+    fill(0, 0)
+    hs.prime(0)
+    for k in range(steps):
+        p = k & 1
+        if k + 1 < steps:
+            fill(1 - p, k + 1)
+        hs.launch(p)
+        if k >= 1:
+            hs.wait(p)
+            got[k - 1] = torch.from_numpy(hs.result(1 - p).copy())      # launch(p) downloaded the previous batch
+    hs.flush((steps - 1) & 1)
+    got[steps - 1] = torch.from_numpy(hs.result((steps - 1) & 1).copy())
+    assert sorted(got) == list(range(steps)) and all(torch.equal(got[k], want[k]) for k in range(steps))
+    assert model.keep_predicted_image is True and model.generator.defer_range_check is False

@@ -8,6 +8,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import _toollib  # noqa: E402,F401  (LAMA_TOOL_LIB=<path>: another build of the library)
 from lama_amd import _lib as L  # noqa: E402
 
 

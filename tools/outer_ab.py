@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timings of the eight OUTER layers of the generator at BASELINE configs[1] shapes (B = 8, 512 x 512): stem, down1-3, up1-3, head -- each launched through
 the C ABI on rotated operand sets (inputs / outputs do not sit in the Infinity Cache), medians of HIP-event pairs.  For same-box A/B runs of the
-profiling library's switches:   LAMA_HIP_LIB=lama_amd/lib/liblama_hip_prof.so LAMA_CT=3 python tools/outer_ab.py [names...]
+profiling library's switches:   LAMA_TOOL_LIB=lama_amd/lib/liblama_hip_prof.so LAMA_CT=3 python tools/outer_ab.py [names...]
 Prints one line per layer: name, median us, min us, checksum of the output (so that two variants can be compared for equality)."""
 import os
 import sys
@@ -10,6 +10,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import _toollib  # noqa: E402,F401  (LAMA_TOOL_LIB=<path>: another build of the library)
 from lama_amd import _lib as L  # noqa: E402
 
 LAYERS = {           # name: (cin, cout, k, H, W, stride, transposed, pad)
@@ -30,7 +31,7 @@ def main():
     lib = L.get_lib()
     dev, B, nrot = 'cuda', 8, int(os.environ.get('KBENCH_ROT', '3'))
     g = torch.Generator().manual_seed(0)
-    tag = ' '.join(f'{k}={v}' for k, v in sorted(os.environ.items()) if k.startswith('LAMA_') and k != 'LAMA_HIP_LIB')
+    tag = ' '.join(f'{k}={v}' for k, v in sorted(os.environ.items()) if k.startswith('LAMA_') and k != 'LAMA_TOOL_LIB')
     for name in names:
         cin, cout, k, H, W, stride, tr, pad = LAYERS[name]
         x = [torch.randn(B, cin, H, W, generator=g).to(dev) for _ in range(nrot)]

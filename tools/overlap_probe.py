@@ -6,6 +6,7 @@ import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import _toollib  # noqa: E402,F401  (LAMA_TOOL_LIB=<path>: another build of the library)
 from lama_amd import _lib as L  # noqa: E402
 from lama_amd import ffc as F  # noqa: E402
 

@@ -5,6 +5,7 @@
 #
 # steps (run in the order given):
 #   tests[:<pytest -k expr>]   pytest -m gpu (optionally -k expr)                          -> pytest_gpu.log
+#   testsall                   pytest -m gpu without -x (every failure listed)
 #   smoke                      __graft_entry__.smoke()
 #   bench[:<extra flags>]      python bench.py <flags>                                     -> bench.json (+ one-line digest)
 #   quick                      bench without the cpu / f32 / eager / configs legs          -> bench_quick.json
@@ -15,7 +16,8 @@
 #   kbench                     per-kernel timings, operands rotated out of the Infinity Cache (KBENCH_ROT=6)
 #   power                      MFMA sustained-rate micro-benchmark (tools/ubench/mfma_power.hip)
 #   ab:<ENV>=<v1>,<v2>[,...]   same-box A/B of an environment switch of the PROFILING library, two rounds   -> ab_<ENV>.txt
-#   ablib:<path/base.so>       same-box A/B of another build of the library against the in-tree one (LAMA_HIP_LIB)
+#   ablib:<path/base.so>       same-box A/B of another build of the library against the in-tree one (bench.py --lib)
+#   sh:<command>               bash -c <command>  (quote the step)                         -> sh_<hash>.log
 #   py:<script> [args]         python <script> args  (quote the step)                      -> py_<script>.log
 #   statspy:<script> [args]    rocprofv3 kernel stats of python <script> args              -> kernel_stats_<script>.csv
 TAG=${1:?usage: session.sh <tag> <step>...}; shift
@@ -30,7 +32,7 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r, f = d.get('roofline') or {}, d.get('roofline_ffc') or {}
 print('bench:', d['value'], d['unit'], d['ms_per_step'], 'ms | roofline', r.get('kernel'), r.get('achieved'), 'TF frac', r.get('frac'),
       '| ffc', f.get('avg_us'), 'us frac', f.get('frac'), 'traffic', f.get('traffic'))
-for k in ('pytorch_rocm_eager', 'exact_f32_leg', 'cpu_baseline', 'configs2_fp16_leg', 'configs4_refine_leg', 'value_with_h2d_d2h'):
+for k in ('pytorch_rocm_eager', 'exact_f32_leg', 'cpu_baseline', 'configs2_fp16_leg', 'configs4_refine_leg', 'value_host_fed'):
     if d.get(k):
         print(' ', k, json.dumps(d[k])[:220])
 print('  kernels_us:', json.dumps(d.get('kernels_us'))[:1200])
@@ -42,6 +44,7 @@ for STEP in "$@"; do
   case $KIND in
     tests)  if [ -n "$ARG" ]; then timeout 1500 python -m pytest tests -m gpu -x -q -k "$ARG" > $O/pytest_gpu.log 2>&1; else timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; fi
             tail -5 $O/pytest_gpu.log | tee -a $O/summary.txt ;;
+    testsall) timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -E "^(FAILED|ERROR)" $O/pytest_gpu.log | head -40 | tee -a $O/summary.txt; tail -3 $O/pytest_gpu.log | tee -a $O/summary.txt ;;
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/summary.txt ;;
     bench)  timeout 1200 python bench.py $ARG > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; digest $O/bench.json | tee -a $O/summary.txt ;;
     quick)  timeout 400 python bench.py $QUICK > $O/bench_quick.json 2> $O/bench_quick.err; tail -c 300 $O/bench_quick.err; digest $O/bench_quick.json | tee -a $O/summary.txt ;;
@@ -65,14 +68,15 @@ d=json.loads(sys.stdin.read()); print('$1 x $2:', d['value'], 'images/s', d['ms_
     ab)     ENVN=${ARG%%=*}; VALS=$(echo ${ARG#*=} | tr ',' ' ')
             for i in 1 2; do for v in $VALS; do
               echo -n "$ENVN=$v: " | tee -a $O/ab_$ENVN.txt
-              env LAMA_HIP_LIB=$PWD/lama_amd/lib/liblama_hip_prof.so $ENVN=$v timeout 300 python bench.py $QUICK 2>/dev/null | tail -1 | python -c "
+              env $ENVN=$v timeout 300 python bench.py $QUICK --lib lama_amd/lib/liblama_hip_prof.so 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms', 'ffc', (d.get('roofline_ffc') or {}).get('avg_us'))" | tee -a $O/ab_$ENVN.txt; done; done
             cat $O/ab_$ENVN.txt >> $O/summary.txt ;;
     ablib)  for i in 1 2; do for v in base new; do
-              if [ $v = base ]; then export LAMA_HIP_LIB=$PWD/$ARG; else unset LAMA_HIP_LIB; fi
-              echo "$v: $(timeout 300 python bench.py $QUICK 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')" | tee -a $O/ablib.txt; done; done; unset LAMA_HIP_LIB
+              if [ $v = base ]; then LIBARG="--lib $ARG"; else LIBARG=""; fi
+              echo "$v: $(timeout 300 python bench.py $QUICK $LIBARG 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')" | tee -a $O/ablib.txt; done; done
             cat $O/ablib.txt >> $O/summary.txt ;;
+    sh)     timeout 900 bash -c "$ARG" > $O/sh_$(echo "$ARG" | md5sum | cut -c1-6).log 2>&1; tail -40 $O/sh_$(echo "$ARG" | md5sum | cut -c1-6).log | tee -a $O/summary.txt ;;
     py)     set -- $ARG; timeout 900 python "$@" > $O/py_$(basename $1 .py).log 2>&1; tail -40 $O/py_$(basename $1 .py).log | tee -a $O/summary.txt ;;
     *)      echo "unknown step $STEP" | tee -a $O/summary.txt ;;
   esac

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of the Winograd local conv (wino_gemm_kernel, LAMA_WG_TRACE; profiling library).
-usage: LAMA_HIP_LIB=lama_amd/lib/liblama_hip_prof.so wg_trace.py [H=64] [nrot=4]"""
+usage: LAMA_TOOL_LIB=lama_amd/lib/liblama_hip_prof.so wg_trace.py [H=64] [nrot=4]"""
 import os
 import sys
 
@@ -12,6 +12,7 @@ H = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 nrot = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 buf = torch.zeros(2048 * 16, dtype=torch.int64, device='cuda')
 os.environ['LAMA_WG_TRACE'] = hex(buf.data_ptr())
+import _toollib  # noqa: E402,F401  (LAMA_TOOL_LIB=<path>: another build of the library)
 from lama_amd import _lib as L  # noqa: E402
 
 lib = L.get_lib()

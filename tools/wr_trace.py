@@ -10,6 +10,7 @@ sys.path.insert(0, ROOT)
 name = sys.argv[1] if len(sys.argv) > 1 else 'fuconv'
 buf = torch.zeros(4096 * 32, dtype=torch.int64, device='cuda')
 os.environ['LAMA_CW_TRACE'] = hex(buf.data_ptr())
+import _toollib  # noqa: E402,F401  (LAMA_TOOL_LIB=<path>: another build of the library)
 from lama_amd import _lib as L  # noqa: E402
 
 lib = L.get_lib()
