@@ -184,24 +184,32 @@ def _write_png(path: str, rgb: np.ndarray):
 
 class HostFedStep:
     """One predict step -- mask binarisation (bin/predict.py:84), mask-compose + generator + blend (trainers/default.py:56-71), u8 HWC
-    quantisation (bin/predict.py:92) -- fed from / drained to pinned HOST buffers, double-buffered, as ONE hipGraph launch per step:
+    quantisation (bin/predict.py:92) -- fed from / drained to pinned HOST buffers, double-buffered:
 
-        launch(p):   H2D  host input set 1-p -> device set 1-p        (the NEXT batch)
+        launch(p):   H2D  host input set 1-p -> device set 1-p        (the NEXT batch; copy stream)
                   || compute on device set p -> u8[p]                 (THIS batch)
-                  || D2H  u8[1-p] -> host result set 1-p              (the PREVIOUS batch; ``drain``)
+                  || D2H  u8[1-p] -> host result set 1-p              (the PREVIOUS batch; copy stream; ``drain``)
 
-    The three are parallel branches INSIDE the captured graph.  Round 4 measured that on ROCm 7.2 a graph replay does not run beside copies
-    issued on other streams (bench.py: 788 images/s around the replay, 819 with plain launches, 825 with resident inputs): as nodes of the
-    same graph the copies overlap the kernels and the ~270 launches of a forward still cost one hipGraphLaunch.  The caller alternates
-    p = 0, 1, 0, ...: it fills host set 1-p before ``launch(p)`` (after ``wait`` has told it that the launch that last read that set is
-    complete), calls ``prime(p0)`` once before the first launch and ``flush(p_last)`` after the last.  ``drain=False`` (multi-rank: the results go
-    through the gather instead) leaves the D2H branch out.  On a CPU device (the emulator tests) the same body runs eagerly, unpinned."""
+    ``mode='streams'`` (default): the batch's launches are plain launches on the caller's stream, the two copies run on streams of their own,
+    forked and joined by events.  ``mode='graph'``: the three as parallel branches INSIDE one captured hipGraph per parity -- built in round 5
+    because a replay of the generator's own graph did not run beside copies of OTHER streams (round 4: 788 images/s around the replay, 819
+    with plain launches, 825 resident) -- and measured slower still: ROCm 7.2 executes memcpy nodes of a graph in line with its kernel nodes
+    (same box: 736 images/s, the serial form 740, streams + plain launches 765, resident 800; profiles/r05_host_fed.txt).  So the serving
+    loop pays ~270 plain launches per batch (the host thread has 10 ms of GPU time to issue them in) and keeps its copies overlapped.
 
-    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True):
+    The caller alternates p = 0, 1, 0, ...: it fills host set 1-p before ``launch(p)`` (after ``wait`` has told it that the launch that last
+    read that set is complete), calls ``prime(p0)`` once before the first launch and ``flush(p_last)`` after the last.  ``drain=False``
+    (multi-rank: the results go through the gather instead) leaves the D2H branch out.  On a CPU device (the emulator tests) the same body
+    runs synchronously, unpinned."""
+
+    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'streams'):
         self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
         self.drain, self.binarize = drain, binarize
+        if mode not in ('streams', 'graph'):
+            raise L.LamaError(f'HostFedStep mode {mode!r}: streams or graph')
+        self.mode = mode
         pin = dict(pin_memory=True) if self.on_gpu else {}
         self.h_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
         self.h_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
@@ -293,9 +301,18 @@ class HostFedStep:
             finally:
                 gen.defer_range_check = keep
             return
-        if self.graphs[p] is None:
-            self._capture(p)
-        self.graphs[p].replay()
+        if self.mode == 'graph':
+            if self.graphs[p] is None:
+                self._capture(p)
+            self.graphs[p].replay()
+        else:       # plain launches: the two copies on streams of their own (fork / join by events) beside this batch's ~270 kernel launches
+            gen = self.model.generator
+            keep = (gen.use_graph, gen.defer_range_check)
+            gen.use_graph, gen.defer_range_check = False, True
+            try:
+                self._body(p)
+            finally:
+                gen.use_graph, gen.defer_range_check = keep
         self.done[p].record(torch.cuda.current_stream(self.device))
         self._launched[p] = True
 

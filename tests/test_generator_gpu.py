@@ -413,9 +413,10 @@ def test_reference_units_at_biglama_channel_counts_on_hardware(big, golden_dir):
 
 
 def test_host_fed_step_graph_matches_plain_forward():
-    """lama_amd.predict.HostFedStep on hardware: upload of batch k + 1, compute of batch k and download of batch k - 1 as parallel branches of ONE
-    captured hipGraph per step (VERDICT r4 Next #4) -- six steps with different pinned-host inputs per step deliver, in order and bit for bit,
-    the u8 images of the plain (generator-graph) forward on each batch; the multi-rank form (no download branch) leaves them in u8[p]."""
+    """lama_amd.predict.HostFedStep on hardware: upload of batch k + 1, compute of batch k and download of batch k - 1 per launch -- on copy streams
+    beside plain launches (the default) and as parallel branches of ONE captured hipGraph per step (VERDICT r4 Next #4; measured slower) -- six
+    steps with different pinned-host inputs per step deliver, in order and bit for bit, the u8 images of the plain (generator-graph) forward on
+    each batch; the multi-rank form (no download branch) leaves them in u8[p]."""
     from lama_amd.predict import HostFedStep
     cfg = O.small_config(ngf=16, n_blocks=2)
     sd = {'generator.' + k: v for k, v in O.make_synthetic_state_dict(cfg, seed=3, calib_hw=32).items()}
@@ -432,8 +433,8 @@ def test_host_fed_step_graph_matches_plain_forward():
         u8 = torch.empty(n, H, W, 3, dtype=torch.uint8, device='cuda')
         lib.quantize_u8_hwc(L.view(out), u8, n, H, W, torch.cuda.current_stream().cuda_stream)
         want.append(u8.cpu())
-    for drain in (True, False):
-        hs = HostFedStep(model, n, H, W, 'cuda', drain=drain)
+    for drain, mode in ((True, 'streams'), (False, 'streams'), (True, 'graph'), (False, 'graph')):
+        hs = HostFedStep(model, n, H, W, 'cuda', drain=drain, mode=mode)
 
         def fill(p, k):
             im, mk = hs.host(p)
@@ -458,8 +459,8 @@ def test_host_fed_step_graph_matches_plain_forward():
             got[steps - 1] = torch.from_numpy(hs.result((steps - 1) & 1).copy())
         assert sorted(got) == list(range(steps))
         for k in range(steps):
-            assert torch.equal(got[k], want[k]), (drain, k)
-        assert hs.graphs[0] is not None and hs.graphs[1] is not None
+            assert torch.equal(got[k], want[k]), (drain, mode, k)
+        assert (hs.graphs[0] is not None and hs.graphs[1] is not None) == (mode == 'graph')
     assert model.generator.check_range('cuda') is True and model.generator.use_graph is True
 
 

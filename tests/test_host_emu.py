@@ -476,3 +476,46 @@ def test_host_fed_step_double_buffering():
     got[steps - 1] = torch.from_numpy(hs.result((steps - 1) & 1).copy())
     assert sorted(got) == list(range(steps)) and all(torch.equal(got[k], want[k]) for k in range(steps))
     assert model.keep_predicted_image is True and model.generator.defer_range_check is False
+
+
+def _inner_feature_maps(gen_model, masked_img, levels):
+    """bin/predict_inner_features.py:84-98 verbatim (cv2.imwrite replaced by a dict): the per-level RMS-over-channels feature image."""
+    out = {}
+    max_level = max(levels)
+    feats = masked_img
+    for level_i, level in enumerate(gen_model):
+        feats = level(feats)
+        if level_i in levels:
+            cur_feats = torch.cat([f for f in feats if torch.is_tensor(f)], dim=1) if isinstance(feats, tuple) else feats
+            cur_feat = cur_feats.pow(2).mean(1).pow(0.5).clone()
+            cur_feat -= cur_feat.min()
+            cur_feat /= cur_feat.std()
+            cur_feat = cur_feat.clamp(0, 1) / 1
+            cur_feat = cur_feat.cpu().numpy()[0] * 255
+            out[level_i] = np.clip(cur_feat, 0, 255).astype('uint8')
+        elif level_i >= max_level:
+            break
+    return out
+
+
+def test_predict_inner_features_call_pattern(small):
+    """bin/predict_inner_features.py:56,84-98: ``generator.model`` must be an nn.Sequential that can be walked level by level from the masked
+    image -- tensors up to the first FFC layer, (x_l, x_g) tuples (x_g the int 0 before the last downsampling layer) through the blocks,
+    tensors again behind ConcatTupleLayer -- with an early ``break``; the per-level feature images equal the oracle's to one u8 level."""
+    cfg, sd, gen = small
+    assert isinstance(getattr(gen, 'model', None), torch.nn.Sequential)
+    batch = O.make_synthetic_batch(1, 64, 64, seed=3)
+    img, mask = batch['image'], batch['mask']
+    mask[:] = 0
+    mask[:, :, 32 - 12:32 + 12, 32 - 12:32 + 12] = 1                    # predict_inner_features.py:77-82 (hole_radius)
+    masked_img = torch.cat([img * (1 - mask), mask], dim=1)
+    levels = [0, 1, 2, 4, 5, 6, 7, 8, 10]
+    taps = {}
+    with torch.no_grad():
+        O.generator_forward(masked_img, sd, cfg, taps=taps)
+
+    ref = _inner_feature_maps([(lambda x, i=i: taps[i]) for i in range(len(taps))], masked_img, levels)
+    got = _inner_feature_maps(gen.model, masked_img, levels)
+    assert sorted(got) == sorted(ref) == levels
+    for i in levels:
+        assert got[i].shape == ref[i].shape and np.abs(got[i].astype(int) - ref[i].astype(int)).max() <= 1, i
