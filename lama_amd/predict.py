@@ -190,25 +190,32 @@ class HostFedStep:
                   || compute on device set p -> u8[p]                 (THIS batch)
                   || D2H  u8[1-p] -> host result set 1-p              (the PREVIOUS batch; copy stream; ``drain``)
 
-    ``mode='streams'`` (default): the batch's launches are plain launches on the caller's stream, the two copies run on streams of their own,
-    forked and joined by events.  ``mode='graph'``: the three as parallel branches INSIDE one captured hipGraph per parity -- built in round 5
-    because a replay of the generator's own graph did not run beside copies of OTHER streams (round 4: 788 images/s around the replay, 819
-    with plain launches, 825 resident) -- and measured slower still: ROCm 7.2 executes memcpy nodes of a graph in line with its kernel nodes
-    (same box: 736 images/s, the serial form 740, streams + plain launches 765, resident 800; profiles/r05_host_fed.txt).  So the serving
-    loop pays ~270 plain launches per batch (the host thread has 10 ms of GPU time to issue them in) and keeps its copies overlapped.
+    ``mode='replay'`` (default): the copies run on streams of their own, forked and joined by events, beside the replay of the generator's own
+    hipGraph (+ four plain launches: mask compose, blend, u8).  ``'streams'``: the same around ~270 plain launches.  ``'graph'``: the three as
+    parallel branches INSIDE one captured hipGraph per parity (built in round 5).  Measured (bench.py value_host_fed, images/s; the boxes of
+    the pool differ in GPU AND host speed; profiles/r05_host_fed.txt):
+
+        box (resident)      serial (copies on the compute stream)   replay    streams    graph
+        r4 driver (825)     761                                     788       819        --
+        r05a      (800)     740                                     --        765        736
+        r05b      (817)     754                                     --        740        756
+
+    A replay of a graph overlaps copies of OTHER streams only partly (the r4 result); copy nodes INSIDE a graph run in line with its kernel
+    nodes on ROCm 7.2 (= the serial form); plain launches overlap fully but make the step launch-bound on a slow host (r05b).  'replay' is
+    the form that never loses to the serial one.
 
     The caller alternates p = 0, 1, 0, ...: it fills host set 1-p before ``launch(p)`` (after ``wait`` has told it that the launch that last
     read that set is complete), calls ``prime(p0)`` once before the first launch and ``flush(p_last)`` after the last.  ``drain=False``
     (multi-rank: the results go through the gather instead) leaves the D2H branch out.  On a CPU device (the emulator tests) the same body
     runs synchronously, unpinned."""
 
-    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'streams'):
+    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'replay'):
         self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
         self.drain, self.binarize = drain, binarize
-        if mode not in ('streams', 'graph'):
-            raise L.LamaError(f'HostFedStep mode {mode!r}: streams or graph')
+        if mode not in ('replay', 'streams', 'graph'):
+            raise L.LamaError(f'HostFedStep mode {mode!r}: replay, streams or graph')
         self.mode = mode
         pin = dict(pin_memory=True) if self.on_gpu else {}
         self.h_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
@@ -305,10 +312,10 @@ class HostFedStep:
             if self.graphs[p] is None:
                 self._capture(p)
             self.graphs[p].replay()
-        else:       # plain launches: the two copies on streams of their own (fork / join by events) beside this batch's ~270 kernel launches
-            gen = self.model.generator
+        else:       # the two copies on streams of their own (fork / join by events) beside this batch's compute: the generator's own hipGraph
+            gen = self.model.generator          # replay ('replay') or its ~270 plain launches ('streams')
             keep = (gen.use_graph, gen.defer_range_check)
-            gen.use_graph, gen.defer_range_check = False, True
+            gen.use_graph, gen.defer_range_check = self.mode == 'replay', True
             try:
                 self._body(p)
             finally:

@@ -433,7 +433,7 @@ def test_host_fed_step_graph_matches_plain_forward():
         u8 = torch.empty(n, H, W, 3, dtype=torch.uint8, device='cuda')
         lib.quantize_u8_hwc(L.view(out), u8, n, H, W, torch.cuda.current_stream().cuda_stream)
         want.append(u8.cpu())
-    for drain, mode in ((True, 'streams'), (False, 'streams'), (True, 'graph'), (False, 'graph')):
+    for drain, mode in ((True, 'replay'), (False, 'replay'), (True, 'streams'), (True, 'graph'), (False, 'graph')):
         hs = HostFedStep(model, n, H, W, 'cuda', drain=drain, mode=mode)
 
         def fill(p, k):

@@ -214,7 +214,7 @@ def test_first_iteration_gradient_18_blocks(biglama_module, golden_dir, precs):
     assert corr > 0.999 and abs(norm_ratio - 1.0) < 5e-3, (corr, norm_ratio)
 
 
-@pytest.mark.parametrize('fwd_prec,bwd_prec,bar', [(L.PREC_F32, L.PREC_F32, 1e-3), (L.PREC_F16X3, L.PREC_BF16X3, 1e-2)],
+@pytest.mark.parametrize('fwd_prec,bwd_prec,bar', [(L.PREC_F32, L.PREC_F32, 5e-5), (L.PREC_F16X3, L.PREC_BF16X3, 3e-4)],
                          ids=['exact_f32', 'default_f16x3_fwd_bf16x3_bwd'])
 def test_rear_gradients_18_blocks_strict(biglama_module, fwd_prec, bwd_prec, bar):
     """VERDICT r4 Next #5 -- a check of the reverse pass at FULL depth that depends neither on the optimisation trajectory nor on ReLU-mask
@@ -223,8 +223,9 @@ def test_rear_gradients_18_blocks_strict(biglama_module, fwd_prec, bwd_prec, bar
     the reverse pass), for a fixed random functional gw instead of the L1 loss, against torch autograd through the oracle WITH THE RELU MASKS OF
     THE HIP TAPE (tests/masked_oracle.py).  Without fixed masks the oracle is 5.3e-3 relative L2 from itself under a 1e-7 perturbation of z
     (measured, 128^2 and 256^2: two valid fp32 evaluations flip a handful of the 2e7 ReLUs) -- a bar a 0.5 % systematic error would pass; with
-    them only rounding separates the two gradients.  Bars: 1e-3 relative L2 in exact fp32 (forward + reverse), 1e-2 with the default
-    precisions (f16x3 forward, bf16x3 reverse); the measured values are printed."""
+    them only rounding separates the two gradients.  Measured on the MI355X (gpurun_out/r05b): 2.6e-6 relative L2 (max / gmax 3.4e-6) in exact
+    fp32, 2.4e-5 with the default precisions (f16x3 forward, bf16x3 reverse) -- and 8.7e-3 / 1.2e-2 against autograd with its OWN masks, which
+    is the flip noise the other gradient tests have to allow.  Bars: 5e-5 / 3e-4 relative L2 and 5x that for the largest element."""
     from tests import masked_oracle as MO
     model, _ = biglama_module
     gen = model.generator

@@ -23,6 +23,9 @@ KEYS = [   # (bench key, [kernel-name regex ...] summed, algorithmic bytes, note
     ('conv1x1_cin384_cout384_64x33', [r'gemm1x1_wk_kernel'], int(2 * 4 * B * 384 * 64 * 33 + 589824), 'spectral 1x1 of the FourierUnit'),
     ('conv1x1_cin384_cout192_64x64', [r'gemm1x1_w4_kernel_f16x3<6, 2, false'], MB(384, 192) + 294912, 'SpectralTransform.conv1 as a launch of its own (first residual layer only)'),
     ('rfft2_192x64x64', [r'^void rfft2_ip64_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33), 'rfft2 of 8 x 192 planes of 64 x 64'),
+    ('rfft2_192x64x64+wino_out', [r'rfft2_ip64_wino_out_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33) + 4 * 4 * B * 128 * 64 * 64 + (18 * MB(128, 128) + 17 * MB(128)) // 35,
+     'the FourierUnit\'s first launch AS THE TIMED REGION ISSUES IT (round 4): rfft2 of 8 x 192 planes + the Winograd output transform of the previous '
+     'layer\'s local conv riding in it (partial sums 4 x [8,128,64,64] in, residual in every second layer, y out)'),
     ('irfft2_192x64x64', [r'^void irfft2_ip64_kernel'], int(2 * MB(192) + 4 * B * 384 * 64 * 33), 'irfft2 + the x + fu(x) add'),
     ('conv3x3T_up1_up2_up3_average', [r'convt2_kernel'], int(4 * B * (512 * 64 * 64 + 256 * 128 * 128 + 256 * 128 * 128 + 128 * 256 * 256 + 128 * 256 * 256 + 64 * 512 * 512) / 3),
      'the three ConvTranspose2d launches (one persistent grid size: the profiler cannot tell them apart): average of up1, up2, up3'),

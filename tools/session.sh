@@ -58,7 +58,8 @@ for STEP in "$@"; do
     pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
     pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
               (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
-              f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f | tee $O/pmc_bench_$CNT.txt | head -40 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done ;;
+              f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f > $O/pmc_bench_$CNT.txt && grep -E "conv_wr_kernel|wino_|gemm1x1_wk|fft2_ip64|convt2|head7|stem7" $O/pmc_bench_$CNT.txt | cut -c1-60,118-200 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done
+              python tools/pmc_bench_to_json.py $O/pmc.json $O/pmc_bench_FETCH_SIZE.txt $O/pmc_bench_WRITE_SIZE.txt | tee -a $O/summary.txt ;;
     shapes) for cfg in "4 1024" "4 256" "1 512" "1 2048"; do set -- $cfg
               LAMA_BENCH_BATCH=$1 LAMA_BENCH_RES=$2 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg 2>/dev/null | tail -1 | python -c "
 import sys,json
