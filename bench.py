@@ -582,6 +582,9 @@ def main():
         model.generator.defer_wino_out = bool(int(os.environ['LAMA_DEFER_OUT']))
     if 'LAMA_ALIAS_WINO' in os.environ:       # ... of the Winograd partial sums in the FourierUnit's (dead) spectra
         model.generator.alias_wino = bool(int(os.environ['LAMA_ALIAS_WINO']))
+    if 'LAMA_SPLIT_BATCH' in os.environ:      # ... of the batch as parallel branches of the graph (0 = the generator's rule, 1 = off, 2 / 4 = forced)
+        model.generator.split_batch = int(os.environ['LAMA_SPLIT_BATCH']) or None
+    nsplit = model.generator._split_parts((BATCH, 4, RES, RES), device)
     dt, range_ok = timed_region(loop, args.steps, args.warmup)
     if not range_ok:
         raise SystemExit('bench.py: an activation left the fp16 split\'s range during the timed steps: the run is void')
@@ -651,6 +654,10 @@ def main():
         # (generator.defer_wino_out); here every unit runs its own launches, so that `fourier_unit_*` is the FourierUnit alone and
         # `conv3x3_cin512_*` the local conv with both of its launches (the fused launch is in profiles/*kernel_stats*.csv)
         defer_timed = model.generator.defer_wino_out
+        # per-KERNEL times need every launch alone on the chip: the parts of the batch that the timed region runs side by side
+        # (generator.split_batch) would overlap under the event pairs, so these steps run the one-part plan -- the same kernels over the whole batch
+        split_timed = model.generator.split_batch
+        model.generator.split_batch = 1
         kern_seq = {}
         if defer_timed:
             # first the timed region's OWN launch sequence (VERDICT r4 Next #4): `fourier_unit_*` then brackets rfft2_ip64_wino_out_kernel (the
@@ -678,6 +685,7 @@ def main():
         kern = timer.summary()
         _ffc2._DEFAULT_EXEC.cooperative_serial = False
         model.generator.defer_wino_out = defer_timed
+        model.generator.split_batch = split_timed
         model.generator.overlap_streams = bool(int(os.environ.get('LAMA_OVERLAP_STREAMS', '1')))   # back to the timed configuration
         model.generator._plans.clear()
         dom = max((k for k in kern if k.startswith('conv')), key=lambda k: kern[k]['total_us'])
@@ -847,7 +855,8 @@ def main():
             'config': {'workload': f'big-lama FFCResNetGenerator {RES}x{RES} batch={BATCH}/GPU fp32 (BASELINE configs[1]), '
                                    f'mask-compose + generator + blend + u8, random-init weights',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
-                       'hip_graph': not args.no_graph, 'precision': args.precision},
+                       'hip_graph': not args.no_graph, 'precision': args.precision,
+                       'split_batch': f'{nsplit} parts of {BATCH // nsplit} images as parallel branches of the one hipGraph (generator.split_batch)' if nsplit > 1 else 1},
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
             'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg,
             'value_host_fed': None if dt_replay is None else dict(

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 108
+#define LAMA_HIP_VERSION 109
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -108,6 +108,14 @@ typedef struct lama_conv2d_args {
     int32_t flags;
 } lama_conv2d_args;
 #define LAMA_CONV_COOPERATIVE 1
+/* (v109) bits 8..10: log2 of the number of SIBLING launches that run at the same time as this one -- the parts of a batch that the host runs as
+ * parallel branches of one hipGraph (lama_amd: generator.split_batch).  A launch over 1 / 2^n of the batch then takes the kernel geometry the WHOLE
+ * batch would take (one 12-wave workgroup per 128-pixel tile of the global branch, with the optional fused conv1; the all-of-K-in-one-wave spectral
+ * GEMM; no split-K in the Winograd conv) instead of the geometry that lets a lone small launch fill the chip: n siblings fill it together.
+ * Same results as the unflagged launch up to fp32 summation order -- and bit-identical to the launch over the whole batch. */
+#define LAMA_CONV_SIBLINGS_SHIFT 8
+#define LAMA_CONV_SIBLINGS_MASK (7 << LAMA_CONV_SIBLINGS_SHIFT)
+#define LAMA_CONV_SIBLINGS_LOG2(flags) (((flags) & LAMA_CONV_SIBLINGS_MASK) >> LAMA_CONV_SIBLINGS_SHIFT)
 /* (v108, lama_winograd_conv3x3_fwd only) launch the GEMM half only; the caller owes the output transform -- lama_winograd_out_fwd or
  * lama_rfft2_winograd_out_fwd with the SAME arguments and workspace -- before anything reads y */
 #define LAMA_CONV_DEFER_OUT 2
@@ -195,6 +203,13 @@ size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, int32_t h, in
 int lama_fourier_unit_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
                           const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision, void* workspace,
                           size_t workspace_bytes, uint32_t* range_flag);
+/* (v109) the superset of lama_fourier_unit_fwd and lama_fourier_unit_winograd_out_fwd (wino_args NULL = no deferred output transform) with the
+ * LAMA_CONV_* flags of its spectral 1x1 launch (ffc.py:100-101) -- LAMA_CONV_SIBLINGS_* when the FourierUnit runs on a part of the batch beside
+ * its siblings. */
+int lama_fourier_unit_ex_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias, const lama_tensor* y,
+                             int32_t batch, int32_t add_input, int32_t precision, void* workspace, size_t workspace_bytes,
+                             uint32_t* range_flag, int32_t flags, const lama_conv2d_args* wino_args, void* wino_workspace,
+                             size_t wino_workspace_bytes);
 
 /* masked_img = cat(img*(1-mask), mask), trainers/default.py:59,67-68.  img [B,3,H,W], mask [B,1,H,W] -> out [B,4,H,W] */
 int lama_mask_compose_fwd(void* stream, const lama_tensor* image, const lama_tensor* mask, const lama_tensor* out,

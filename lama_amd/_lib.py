@@ -17,8 +17,9 @@ PAD_ZERO, PAD_REFLECT = 0, 1
 PREC_F32, PREC_BF16X3, PREC_F16X3, PREC_F16 = 0, 1, 2, 3
 CONV_COOPERATIVE = 1
 CONV_DEFER_OUT = 2          # lama_winograd_conv3x3_fwd: the GEMM launch only (include/lama_hip.h)
+CONV_SIBLINGS_SHIFT = 8     # (v109) bits 8..10: log2 of the number of sibling launches that share the chip with this one
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 108      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 109      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -111,6 +112,8 @@ class LamaLib:
         L.lama_fourier_unit_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz, vp]
         L.lama_fourier_unit_winograd_out_fwd.restype = C.c_int
         L.lama_fourier_unit_winograd_out_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz, vp, C.POINTER(Conv2dArgs), vp, sz]
+        L.lama_fourier_unit_ex_fwd.restype = C.c_int
+        L.lama_fourier_unit_ex_fwd.argtypes = [vp, T, vp, vp, T, i32, i32, i32, vp, sz, vp, i32, C.POINTER(Conv2dArgs), vp, sz]
         L.lama_mask_compose_fwd.restype = C.c_int
         L.lama_mask_compose_fwd.argtypes = [vp, T, T, T, i32]
         L.lama_blend_fwd.restype = C.c_int
@@ -192,9 +195,10 @@ class LamaLib:
                pad_mode: int = PAD_REFLECT, transposed: bool = False, bias: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, resid: Optional[Tensor4] = None, x2: Optional[Tensor4] = None,
                w2_packed: Optional[torch.Tensor] = None, precision: int = PREC_F32, stream: int = 0,
-               range_flag: Optional[torch.Tensor] = None, fuse1: Optional[tuple] = None, cooperative: bool = False):
+               range_flag: Optional[torch.Tensor] = None, fuse1: Optional[tuple] = None, cooperative: bool = False, siblings_log2: int = 0):
         """``fuse1`` = (packed conv1 weights with the channel order of fuse1_channel_order(), BatchNorm shift [192], x1 view): the NEXT
-        layer's SpectralTransform.conv1 in the epilogue of this (global-branch) launch -- lama_conv2d_args.fuse1_*."""
+        layer's SpectralTransform.conv1 in the epilogue of this (global-branch) launch -- lama_conv2d_args.fuse1_*.  ``siblings_log2`` (v109):
+        this launch covers 1 / 2^n of a batch whose other parts run beside it (LAMA_CONV_SIBLINGS_*)."""
         a = Conv2dArgs()
         a.x, a.w_packed = x, w_packed.data_ptr()
         a.kh = a.kw = k
@@ -209,7 +213,7 @@ class LamaLib:
         a.range_flag = None if range_flag is None else range_flag.data_ptr()
         if fuse1 is not None:
             a.fuse1_w, a.fuse1_bias, a.fuse1_y = fuse1[0].data_ptr(), fuse1[1].data_ptr(), fuse1[2]
-        a.flags = CONV_COOPERATIVE if cooperative else 0      # another stream runs beside this launch (lama_conv2d_args.flags)
+        a.flags = (CONV_COOPERATIVE if cooperative else 0) | (int(siblings_log2) << CONV_SIBLINGS_SHIFT)   # lama_conv2d_args.flags
         self.check(self._l.lama_conv2d_fwd(stream, C.byref(a)), 'lama_conv2d_fwd')
 
     # -- Winograd F(2x2, 3x3) form of the stride-1 3x3 reflect conv (lama_winograd_*) -----------------
@@ -244,7 +248,7 @@ class LamaLib:
 
     def winograd_conv3x3(self, x: Tensor4, w_packed: torch.Tensor, y: Tensor4, batch: int, ws: torch.Tensor, bias: Optional[torch.Tensor] = None,
                          act: int = ACT_NONE, resid: Optional[Tensor4] = None, precision: int = PREC_F16X3, stream: int = 0,
-                         range_flag: Optional[torch.Tensor] = None, pad_mode: int = PAD_REFLECT, defer_out: bool = False):
+                         range_flag: Optional[torch.Tensor] = None, pad_mode: int = PAD_REFLECT, defer_out: bool = False, siblings_log2: int = 0):
         """``defer_out`` (v108): only the GEMM launch; returns the argument block the caller hands to ``winograd_out`` / ``rfft2_wino_out``
         (with the same workspace) before anything reads y."""
         a = Conv2dArgs()
@@ -257,7 +261,7 @@ class LamaLib:
             a.resid = resid
         a.y, a.batch, a.precision = y, batch, precision
         a.range_flag = None if range_flag is None else range_flag.data_ptr()
-        a.flags = CONV_DEFER_OUT if defer_out else 0
+        a.flags = (CONV_DEFER_OUT if defer_out else 0) | (int(siblings_log2) << CONV_SIBLINGS_SHIFT)
         self.check(self._l.lama_winograd_conv3x3_fwd(stream, C.byref(a), ws.data_ptr(), ws.numel() * ws.element_size()), 'lama_winograd_conv3x3_fwd')
         return a if defer_out else None
 
@@ -310,9 +314,18 @@ class LamaLib:
 
     def fourier_unit(self, x: Tensor4, w_packed: torch.Tensor, bias: torch.Tensor, y: Tensor4, batch: int, add_input: bool,
                      ws: torch.Tensor, precision: int = PREC_F32, stream: int = 0, range_flag: Optional[torch.Tensor] = None,
-                     wino_out: Optional[tuple] = None):
+                     wino_out: Optional[tuple] = None, siblings_log2: int = 0):
         """``wino_out`` = (argument block of a ``winograd_conv3x3(..., defer_out=True)`` call, its workspace): that conv's output transform runs
-        inside this FourierUnit's rfft2 launch (lama_fourier_unit_winograd_out_fwd, v108)."""
+        inside this FourierUnit's rfft2 launch (lama_fourier_unit_winograd_out_fwd, v108).  ``siblings_log2`` (v109): lama_fourier_unit_ex_fwd."""
+        if siblings_log2:
+            wa, wws = wino_out if wino_out is not None else (None, None)
+            self.check(self._l.lama_fourier_unit_ex_fwd(stream, C.byref(x), w_packed.data_ptr(), bias.data_ptr(), C.byref(y), batch,
+                                                        int(add_input), precision, ws.data_ptr(), ws.numel() * ws.element_size(),
+                                                        None if range_flag is None else range_flag.data_ptr(), int(siblings_log2) << CONV_SIBLINGS_SHIFT,
+                                                        None if wa is None else C.byref(wa), None if wws is None else wws.data_ptr(),
+                                                        0 if wws is None else wws.numel() * wws.element_size()),
+                       'lama_fourier_unit_ex_fwd')
+            return
         if wino_out is not None:
             wa, wws = wino_out
             self.check(self._l.lama_fourier_unit_winograd_out_fwd(stream, C.byref(x), w_packed.data_ptr(), bias.data_ptr(), C.byref(y), batch,

@@ -244,7 +244,7 @@ extern "C" size_t lama_fourier_unit_workspace_bytes(int32_t batch, int32_t C, in
 static int fourier_unit_impl(void* stream, const lama_tensor* x, const void* w_packed, const float* bias,
                              const lama_tensor* y, int32_t batch, int32_t add_input, int32_t precision,
                              void* workspace, size_t workspace_bytes, uint32_t* range_flag,
-                             const lama_conv2d_args* wino_args, void* wino_ws, size_t wino_ws_bytes) {
+                             const lama_conv2d_args* wino_args, void* wino_ws, size_t wino_ws_bytes, int32_t flags = 0) {
     if (!x || !y || !x->ptr || !y->ptr || !w_packed || batch <= 0) return LAMA_ERR_BAD_ARG;
     if (x->C != y->C || x->H != y->H || x->W != y->W) return LAMA_ERR_BAD_ARG;
     const int C = x->C, h = x->H, w = x->W, wf = w / 2 + 1;
@@ -280,6 +280,7 @@ static int fourier_unit_impl(void* stream, const lama_tensor* x, const void* w_p
     a.batch = batch;
     a.precision = precision;
     a.range_flag = range_flag;
+    a.flags = flags & LAMA_CONV_SIBLINGS_MASK;      // a part of the batch beside its siblings: the whole batch's kernel (v109)
     rc = lama_conv2d_fwd(stream, &a);
     if (rc) return rc;
     return lama_irfft2_fwd(stream, &s2, add_input ? x : nullptr, y, batch, fws, fws_bytes);
@@ -300,5 +301,15 @@ extern "C" int lama_fourier_unit_winograd_out_fwd(void* stream, const lama_tenso
     if (!wino_args || !wino_workspace) return LAMA_ERR_BAD_ARG;
     return fourier_unit_impl(stream, x, w_packed, bias, y, batch, add_input, precision, workspace, workspace_bytes, range_flag, wino_args,
                              wino_workspace, wino_workspace_bytes);
+}
+
+// (v109) both of the above + the LAMA_CONV_* flags of the spectral 1x1 launch
+extern "C" int lama_fourier_unit_ex_fwd(void* stream, const lama_tensor* x, const void* w_packed, const float* bias, const lama_tensor* y,
+                                        int32_t batch, int32_t add_input, int32_t precision, void* workspace, size_t workspace_bytes,
+                                        uint32_t* range_flag, int32_t flags, const lama_conv2d_args* wino_args, void* wino_workspace,
+                                        size_t wino_workspace_bytes) {
+    if (wino_args && !wino_workspace) return LAMA_ERR_BAD_ARG;
+    return fourier_unit_impl(stream, x, w_packed, bias, y, batch, add_input, precision, workspace, workspace_bytes, range_flag, wino_args,
+                             wino_workspace, wino_workspace_bytes, flags);
 }
 

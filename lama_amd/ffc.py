@@ -126,6 +126,10 @@ class _Exec:
         self._depth = 0
         self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
+        self.fuse1_min_tiles = 192        # conv1 of the next layer rides in the global launch from this many 128-pixel tiles on (FFC.launch)
+        # log2 of the number of parts of a batch that run side by side as parallel branches of one hipGraph (FFCResNetGenerator.split_batch):
+        # set while the launches of ONE part are issued; every conv / FourierUnit / Winograd launch carries it (LAMA_CONV_SIBLINGS_*, v109)
+        self.siblings_log2 = 0
         self.winograd = True              # the local 3x3 conv of a two-branch FFC layer as Winograd F(2x2, 3x3) where the shape allows (wino_dev.inc)
         self.local_first = True           # capture order at the fork: the first successor of a hipGraph node stays on its queue
         self.cooperative_serial = False   # tests: the one-stream launch order with the overlapped order's kernel geometry (bit-equal results)
@@ -199,14 +203,18 @@ class _Exec:
 
     def conv2d(self, *a, **kw):
         flag = self._cur_flag if kw.get('precision') in (L.PREC_F16X3, L.PREC_F16) else None
+        if self.siblings_log2:
+            kw['siblings_log2'] = self.siblings_log2
         self.lib.conv2d(*a, range_flag=flag, **kw)
 
     def fourier_unit(self, *a, precision: int = L.PREC_F32, stream: int = 0, wino_out=None):
         flag = self._cur_flag if precision in (L.PREC_F16X3, L.PREC_F16) else None
-        self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag, wino_out=wino_out)
+        self.lib.fourier_unit(*a, precision=precision, stream=stream, range_flag=flag, wino_out=wino_out, siblings_log2=self.siblings_log2)
 
     def winograd_conv3x3(self, *a, precision: int = L.PREC_F16X3, **kw):
         flag = self._cur_flag if precision == L.PREC_F16X3 else None
+        if self.siblings_log2:
+            kw['siblings_log2'] = self.siblings_log2
         return self.lib.winograd_conv3x3(*a, precision=precision, range_flag=flag, **kw)
 
 
@@ -545,9 +553,9 @@ class FFC(_HipModule):
         shape_key = (tuple(src.shape), prec)
         # only when the global launch fills the chip (one 128-pixel tile per CU and more): on a few dozen tiles the epilogue GEMM runs on
         # a few dozen CUs while a launch of its own would use all of them (4 x 256^2: 587 -> 648 images/s with conv1 on its own)
-        tiles = B * ((dst.shape[2] * dst.shape[3] + 127) // 128)
+        tiles = (B * ((dst.shape[2] * dst.shape[3] + 127) // 128)) << ex.siblings_log2     # (a part of a batch counts with its siblings)
         if (fuse_next is not None and f.kernel_size == 3 and f.stride == 1 and ocg == 384 and shape_key not in ex.no_fuse1
-                and (tiles >= 192 or ex.injected)):
+                and (tiles >= ex.fuse1_min_tiles or ex.injected)):
             fuse1 = fuse_next.fuse1_operands(scratch['x1'])
         gargs = (L.view(src, 0, cl), pk['w_l2g'], L.view(dst, ocl, ocg), B, 3, 1, pad, L.PAD_REFLECT, False, pk['b_g'], act,
                  None if resid is None else L.view(resid, ocl, ocg))
@@ -953,6 +961,16 @@ class FFCResNetGenerator(_HipModule):
         # activation-buffer sets (+ captured hipGraphs) per input shape: 2.2 GB at 8 x 512^2, so only the most recently used
         # ``max_plans`` shapes are kept (a directory of many image sizes would otherwise fill HBM)
         self.max_plans = 4
+        # Parts of a batch as PARALLEL BRANCHES of the plan (round 5).  Every launch of the one-stream forward fills the chip with workgroups that run
+        # the same phase at the same time, and between two launches the chip drains and refills (~190 boundaries per forward).  Two (four) parts of
+        # the batch, each with its own buffers, issued on streams of their own inside the SAME captured hipGraph (kernel branches of a graph run
+        # side by side on ROCm 7.2; two graphs do not) put one part's memory-bound launches beside the other's MFMA-bound ones and fill each
+        # other's boundaries: 8 x 512^2 +3-5 %, 4 x 1024^2 +7-8 %, 16 x 512^2 in four parts +18 % (same box, bit-identical output:
+        # profiles/r05_split_batch.txt).  Each part's launches tell the library that they share the chip (LAMA_CONV_SIBLINGS_*, v109) and get the
+        # kernel geometry of the whole batch.  None = by shape (_split_parts: GPU, split precisions, at least 128 bottleneck tiles per part),
+        # 1 = off, 2 / 4 = forced.
+        self.split_batch = None
+        self.n_downsampling = n_downsampling
         # False: ``forward`` returns the plan's own output buffer instead of a copy of it -- for callers that consume the result before this
         # generator's next forward of the same shape (DefaultInpaintingTrainingModule with keep_predicted_image = False: blend reads it at once)
         self.clone_output = True
@@ -1083,6 +1101,8 @@ class FFCResNetGenerator(_HipModule):
                     fuse=self.fuse_conv1 or (serial and self.fuse_conv1 is not False and self.fuse_conv1_serial))
 
     def _run_plan(self, plan, x):
+        if 'parts' in plan:
+            return self._run_split(plan, x)
         bufs = plan['bufs']
 
         def B(name):
@@ -1154,13 +1174,69 @@ class FFCResNetGenerator(_HipModule):
         self.set_precision(L.PREC_BF16X3)
         return False
 
+    def _split_parts(self, shape, device) -> int:
+        """How many parallel parts the plan of this input shape has (``split_batch``)."""
+        B = int(shape[0])
+        n = self.split_batch
+        if n is None:
+            if torch.device(device).type != 'cuda' or self.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
+                return 1
+            h, w = int(shape[2]) >> self.n_downsampling, int(shape[3]) >> self.n_downsampling
+            tiles = B * ((h * w + 127) // 128)              # 128-pixel tiles of the bottleneck: every part keeps >= 128 of them (half the chip)
+            n = 4 if tiles >= 512 else (2 if tiles >= 256 else 1)
+            while n > 1 and B % n:
+                n //= 2
+            return n
+        n = int(n)
+        if n < 1 or n & (n - 1) or n > 4 or B % n:
+            raise LamaError(f'split_batch={n}: 1, 2 or 4 parts that divide the batch ({B})')
+        return n
+
+    def _build_split_plan(self, shape, device, n: int) -> dict:
+        B = int(shape[0])
+        h = B // n
+        parts = [self._build_plan((h,) + tuple(shape[1:]), device) for _ in range(n)]
+        out_shape = (B,) + tuple(parts[0]['bufs'][parts[0]['out']].shape[1:])
+        out_full = torch.empty(out_shape, device=device, dtype=parts[0]['bufs'][parts[0]['out']].dtype)
+        for i, pl in enumerate(parts):
+            pl['bufs'][pl['out']] = out_full[i * h:(i + 1) * h]       # the parts write their images side by side
+        streams = [torch.cuda.Stream(device=device) for _ in range(n - 1)] if torch.device(device).type == 'cuda' else []
+        return dict(parts=parts, part_batch=h, streams=streams, out_full=out_full, nsplit=n, graph=None, static_in=None, scratch=None, side=None)
+
+    def _run_split(self, plan, x):
+        ex, parts, h = self._exec, plan['parts'], plan['part_batch']
+        main = torch.cuda.current_stream(x.device) if x.is_cuda else None
+        keep = ex.siblings_log2
+        ex.siblings_log2 = len(parts).bit_length() - 1
+        try:
+            for i in range(1, len(parts)):
+                xi = x[i * h:(i + 1) * h]
+                if main is not None:
+                    s = plan['streams'][i - 1]
+                    s.wait_stream(main)                      # fork (captured into the graph as an edge)
+                    with torch.cuda.stream(s):
+                        self._run_plan(parts[i], xi)
+                else:
+                    self._run_plan(parts[i], xi)
+            self._run_plan(parts[0], x[:h])
+            if main is not None:
+                for s in plan['streams']:
+                    main.wait_stream(s)                      # join
+        finally:
+            ex.siblings_log2 = keep
+        return plan['out_full']
+
     def _plan_for(self, shape, device) -> dict:
         key = (tuple(shape), str(device))
+        n = self._split_parts(shape, device)
         plan = self._plans.get(key)
+        if plan is not None and plan.get('nsplit', 1) != n:
+            plan = None                                      # split_batch changed since this plan was built
+            del self._plans[key]
         if plan is None:
             while len(self._plans) >= max(1, self.max_plans):
                 self._plans.popitem(last=False)
-            plan = self._plans[key] = self._build_plan(shape, device)
+            plan = self._plans[key] = self._build_split_plan(shape, device, n) if n > 1 else self._build_plan(shape, device)
         else:
             self._plans.move_to_end(key)
         return plan

@@ -488,3 +488,29 @@ def test_input_buffer_and_unclone_are_the_same_forward(big):
     finally:
         gen.use_graph = False
         gen._plans.clear()
+
+
+def test_split_batch_graph_is_bit_identical(big):
+    """Round 5: 8 x 512^2 as two (auto) / four parallel branches of one captured hipGraph -- the parts' launches carry LAMA_CONV_SIBLINGS_* and take
+    the kernel geometry of the whole batch, so the output equals the one-part plan's BIT FOR BIT, eager and replayed, twice (dirty buffers)."""
+    cfg, sd, gen, TOL = big
+    batch = O.make_synthetic_batch(8, 512, 512, seed=43)
+    xd = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
+    auto = gen._split_parts(xd.shape, xd.device)
+    assert auto == (2 if gen.precision in (L.PREC_F16X3, L.PREC_BF16X3) else 1)
+    assert gen._split_parts((4, 4, 1024, 1024), xd.device) == (4 if auto == 2 else 1) and gen._split_parts((4, 4, 512, 512), xd.device) == 1
+    try:
+        gen.split_batch = 1
+        ref = gen(xd).clone()
+        for n in (2, 4):
+            gen.split_batch = n
+            for graph in (False, True):
+                gen.use_graph = graph
+                gen._plans.clear()
+                assert torch.equal(gen(xd), ref) and torch.equal(gen(xd), ref), (n, graph)
+                assert next(iter(gen._plans.values()))['nsplit'] == n
+    finally:
+        gen.split_batch = None
+        gen.use_graph = False
+        gen._plans.clear()
+    assert gen.check_range(xd.device) is True

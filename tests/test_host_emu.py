@@ -519,3 +519,42 @@ def test_predict_inner_features_call_pattern(small):
     assert sorted(got) == sorted(ref) == levels
     for i in levels:
         assert got[i].shape == ref[i].shape and np.abs(got[i].astype(int) - ref[i].astype(int)).max() <= 1, i
+
+
+def test_split_batch_plan_is_bit_identical(small):
+    """Round 5: the parts of a batch as parallel branches of the plan (generator.split_batch; on the emulator the branches run one after the other):
+    each part has its own buffers, reads its slice of the input, writes its slice of the output and tags its launches as siblings
+    (LAMA_CONV_SIBLINGS_*, v109) -- same bits as the one-part plan; the auto rule never splits on a CPU device."""
+    cfg, sd, gen = small
+    batch = O.make_synthetic_batch(4, 32, 48, seed=21)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    seen = []
+    real = gen._exec.lib.conv2d
+
+    def spy(*a, **kw):
+        seen.append(kw.get('siblings_log2', 0))
+        return real(*a, **kw)
+
+    try:
+        assert gen._split_parts(x.shape, x.device) == 1
+        y1 = gen(x).clone()
+        assert 'parts' not in next(iter(gen._plans.values()))
+        gen._exec.lib.conv2d = spy
+        for n in (2, 4):
+            gen.split_batch = n
+            seen.clear()
+            yn = gen(x).clone()
+            plan = next(iter(gen._plans.values()))
+            assert plan['nsplit'] == n and len(plan['parts']) == n and len(gen._plans) == 1
+            assert torch.equal(yn, y1) and torch.equal(gen(x), y1), n
+            assert seen and all(v == n.bit_length() - 1 for v in seen) and gen._exec.siblings_log2 == 0
+            buf = gen.input_buffer(x.shape, x.device)
+            buf.copy_(x)
+            assert torch.equal(gen(buf), y1)
+        gen.split_batch = 3
+        with pytest.raises(F.LamaError):
+            gen(x)
+    finally:
+        gen._exec.lib.conv2d = real
+        gen.split_batch = None
+        gen._plans.clear()

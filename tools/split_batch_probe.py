@@ -27,6 +27,9 @@ def main():
     model = bench.build_model(dev, L.PREC_F16X3)
     gen = model.generator
     gen.defer_range_check = True
+    if os.environ.get('PROBE_FUSE1'):       # with LAMA_CW_G12=2 (profiling build): conv1 of the next layer rides in the half launches too
+        from lama_amd import ffc as F
+        F._DEFAULT_EXEC.fuse1_min_tiles = int(os.environ['PROBE_FUSE1'])
     img, mask = bench.synthetic_batch(dev, 1234)
     x = torch.cat([img * (1 - mask), mask], 1).contiguous()
     B = x.shape[0]
@@ -47,35 +50,39 @@ def main():
     t_full = timeit(lambda: gen(x), steps)
     print(f'one batch-{B} graph: {t_full:.3f} ms per {B} images', flush=True)
 
-    # two half-batch plans with their own buffers, outputs side by side in one tensor
+    # PROBE_SPLIT part-batch plans with their own buffers, outputs side by side in one tensor
     gen.use_graph = False
-    h = B // 2
-    xa, xb = x[:h], x[h:]
-    pa, pb = gen._build_plan(xa.shape, dev), gen._build_plan(xb.shape, dev)
+    ns = int(os.environ.get('PROBE_SPLIT', '2'))
+    h = B // ns
+    xs = [x[i * h:(i + 1) * h] for i in range(ns)]
+    plans = [gen._build_plan(xi.shape, dev) for xi in xs]
     out = torch.empty_like(ref)
-    pa['bufs'][pa['out']], pb['bufs'][pb['out']] = out[:h], out[h:]
-    s2 = torch.cuda.Stream(device=dev)
+    for i, pl in enumerate(plans):
+        pl['bufs'][pl['out']] = out[i * h:(i + 1) * h]
+    sides = [torch.cuda.Stream(device=dev) for _ in range(ns - 1)]
 
     def both(parallel):
         main_s = torch.cuda.current_stream(dev)
         if parallel:
-            s2.wait_stream(main_s)
-            with torch.cuda.stream(s2):
-                if delay:
-                    torch.cuda._sleep(delay)
-                gen._run_plan(pb, xb)
-            gen._run_plan(pa, xa)
-            main_s.wait_stream(s2)
+            for i, s2 in enumerate(sides):
+                s2.wait_stream(main_s)
+                with torch.cuda.stream(s2):
+                    if delay:
+                        torch.cuda._sleep(delay * (i + 1))
+                    gen._run_plan(plans[i + 1], xs[i + 1])
+            gen._run_plan(plans[0], xs[0])
+            for s2 in sides:
+                main_s.wait_stream(s2)
         else:
-            gen._run_plan(pa, xa)
-            gen._run_plan(pb, xb)
+            for pl, xi in zip(plans, xs):
+                gen._run_plan(pl, xi)
 
     with gen._exec.range_scope(x, gen.precision, deferred=True):
         both(False)                                     # warm-up: packs, builds
         torch.cuda.synchronize()
         err = float((out - ref).abs().max())
-        print(f'two batch-{h} plans, eager: max |diff| vs the batch-{B} plan {err:.2e}', flush=True)
-        for name, par in (('back to back in one graph', False), ('as two parallel branches of one graph', True)):
+        print(f'{ns} batch-{h} plans, eager: max |diff| vs the batch-{B} plan {err:.2e}', flush=True)
+        for name, par in (('back to back in one graph', False), (f'as {ns} parallel branches of one graph', True)):
             g = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -87,7 +94,7 @@ def main():
             out.zero_()
             t = timeit(g.replay, steps)
             err = float((out - ref).abs().max())
-            print(f'two batch-{h} plans {name}: {t:.3f} ms per {B} images ({t_full / t:.3f}x the batch-{B} graph), max |diff| {err:.2e}', flush=True)
+            print(f'{ns} batch-{h} plans {name}: {t:.3f} ms per {B} images ({t_full / t:.3f}x the batch-{B} graph), max |diff| {err:.2e}', flush=True)
     print('range ok:', gen.check_range(dev))
 
 
