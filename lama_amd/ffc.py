@@ -991,8 +991,10 @@ class FFCResNetGenerator(_HipModule):
         super()._invalidate()
         self._plans = collections.OrderedDict()
 
-    def _build_plan(self, shape, device):
-        """Pre-allocate every activation buffer for an input shape and record the launch list."""
+    def _build_plan(self, shape, device, one_stream: bool = False):
+        """Pre-allocate every activation buffer for an input shape and record the launch list.  ``one_stream``: never a second stream inside this
+        plan (the parts of a split plan are branches of their own already: a fork + join per layer INSIDE a branch made hipStreamEndCapture
+        segfault on ROCm 7.2)."""
         layers = list(self.model)
         steps = []
         bufs = {}
@@ -1096,7 +1098,7 @@ class FFCResNetGenerator(_HipModule):
                 scratch['wino'] = ws[:wn.numel()]
             else:
                 scratch['ws'] = wn[:ws.numel()]
-        side = torch.cuda.Stream(device=device) if (self.overlap_streams and not serial and torch.device(device).type == 'cuda') else None
+        side = torch.cuda.Stream(device=device) if (self.overlap_streams and not serial and not one_stream and torch.device(device).type == 'cuda') else None
         return dict(steps=steps, bufs=bufs, scratch=scratch, out=cur, graph=None, static_in=None, side=side,
                     fuse=self.fuse_conv1 or (serial and self.fuse_conv1 is not False and self.fuse_conv1_serial))
 
@@ -1195,7 +1197,7 @@ class FFCResNetGenerator(_HipModule):
     def _build_split_plan(self, shape, device, n: int) -> dict:
         B = int(shape[0])
         h = B // n
-        parts = [self._build_plan((h,) + tuple(shape[1:]), device) for _ in range(n)]
+        parts = [self._build_plan((h,) + tuple(shape[1:]), device, one_stream=True) for _ in range(n)]
         out_shape = (B,) + tuple(parts[0]['bufs'][parts[0]['out']].shape[1:])
         out_full = torch.empty(out_shape, device=device, dtype=parts[0]['bufs'][parts[0]['out']].dtype)
         for i, pl in enumerate(parts):
