@@ -819,6 +819,24 @@ def main():
             c3_leg = dict(error=repr(e)[:300])
         model.generator.set_precision(precision)
 
+    # extra leg (rank 0, N = 1): the same network with SIXTEEN images per step (two batches of 8 in flight: four parts of four images as parallel
+    # branches of the graph).  Not BASELINE's batch (8 per GPU) and never `value`: it shows what the chip does once the parts oversubscribe it
+    b16_leg = None
+    if rank == 0 and world == 1 and not args.no_f32_leg and BATCH == 8 and RES == 512:
+        try:
+            img16, mask16 = torch.cat([img, img.flip(0)], 0), torch.cat([mask, mask.flip(0)], 0)
+            loop16 = StepLoop(model, lib, device, img16, mask16)
+            model.generator.use_graph = not args.no_graph
+            d16, ok16 = timed_region(loop16, max(5, args.steps // 2), 3)
+            b16_leg = dict(value=round(16 * max(5, args.steps // 2) / d16, 2), unit='images/s', ms_per_step=round(d16 / max(5, args.steps // 2) * 1e3, 3),
+                           range_ok=bool(ok16), split_batch=model.generator._split_parts((16, 4, RES, RES), device),
+                           note='16 x 512^2 per step (a serving loop may choose its batch: python -m lama_amd.predict batch_size=16); BASELINE configs[1] is 8')
+            del loop16, img16, mask16
+            model.generator._plans.clear()
+            torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001
+            b16_leg = dict(error=repr(e)[:300])
+
     # extra leg (rank 0, N = 1): BASELINE configs[4] -- refinement of one 2048x2048 image (px_budget 4194304, 15 iterations, 3 scales)
     c5_leg = None
     if rank == 0 and world == 1 and not args.no_f32_leg and BATCH == 8 and RES == 512:
@@ -858,7 +876,7 @@ def main():
                        'hip_graph': not args.no_graph, 'precision': args.precision,
                        'split_batch': f'{nsplit} parts of {BATCH // nsplit} images as parallel branches of the one hipGraph (generator.split_batch)' if nsplit > 1 else 1},
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
-            'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg,
+            'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg, 'batch16_leg': b16_leg,
             'value_host_fed': None if dt_replay is None else dict(
                 value=round(BATCH * args.steps / dt_replay, 3), unit='images/s', ms_per_step=round(dt_replay / args.steps * 1e3, 3),
                 vs_resident=round(dt / dt_replay, 4),

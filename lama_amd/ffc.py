@@ -967,7 +967,7 @@ class FFCResNetGenerator(_HipModule):
         # side by side on ROCm 7.2; two graphs do not) put one part's memory-bound launches beside the other's MFMA-bound ones and fill each
         # other's boundaries: 8 x 512^2 +3-5 %, 4 x 1024^2 +7-8 %, 16 x 512^2 in four parts +18 % (same box, bit-identical output:
         # profiles/r05_split_batch.txt).  Each part's launches tell the library that they share the chip (LAMA_CONV_SIBLINGS_*, v109) and get the
-        # kernel geometry of the whole batch.  None = by shape (_split_parts: GPU, split precisions, at least 128 bottleneck tiles per part),
+        # kernel geometry of the whole batch.  None = by shape (_split_parts: GPU, split precisions, from 256 bottleneck tiles on: four parts, two when 4 does not divide the batch),
         # 1 = off, 2 / 4 = forced.
         self.split_batch = None
         self.n_downsampling = n_downsampling
@@ -1184,9 +1184,9 @@ class FFCResNetGenerator(_HipModule):
             if torch.device(device).type != 'cuda' or self.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
                 return 1
             h, w = int(shape[2]) >> self.n_downsampling, int(shape[3]) >> self.n_downsampling
-            tiles = B * ((h * w + 127) // 128)              # 128-pixel tiles of the bottleneck: every part keeps >= 128 of them (half the chip)
-            n = 4 if tiles >= 512 else (2 if tiles >= 256 else 1)
-            while n > 1 and B % n:
+            tiles = B * ((h * w + 127) // 128)              # 128-pixel tiles of the bottleneck: the parts TOGETHER must fill the chip (one
+            n = 4 if tiles >= 256 else 1                    # 12-wave workgroup per tile and CU), so nothing splits below 256 tiles; four parts
+            while n > 1 and B % n:                          # measured >= two at every size tried (profiles/r05_split_batch.txt)
                 n //= 2
             return n
         n = int(n)

@@ -497,8 +497,9 @@ def test_split_batch_graph_is_bit_identical(big):
     batch = O.make_synthetic_batch(8, 512, 512, seed=43)
     xd = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
     auto = gen._split_parts(xd.shape, xd.device)
-    assert auto == (2 if gen.precision in (L.PREC_F16X3, L.PREC_BF16X3) else 1)
-    assert gen._split_parts((4, 4, 1024, 1024), xd.device) == (4 if auto == 2 else 1) and gen._split_parts((4, 4, 512, 512), xd.device) == 1
+    assert auto == (4 if gen.precision in (L.PREC_F16X3, L.PREC_BF16X3) else 1)
+    assert gen._split_parts((4, 4, 1024, 1024), xd.device) == auto and gen._split_parts((4, 4, 512, 512), xd.device) == 1
+    assert gen._split_parts((6, 4, 512, 512), xd.device) == 1 and gen._split_parts((2, 4, 1024, 1024), xd.device) == (2 if auto == 4 else 1)
     try:
         gen.split_batch = 1
         ref = gen(xd).clone()
@@ -507,7 +508,7 @@ def test_split_batch_graph_is_bit_identical(big):
             for graph in (False, True):
                 gen.use_graph = graph
                 gen._plans.clear()
-                if auto == 2:
+                if auto == 4:
                     assert torch.equal(gen(xd), ref) and torch.equal(gen(xd), ref), (n, graph)
                 else:   # exact fp32: the one-part plan runs the local conv beside the spectral branch in its cooperative geometry, the parts are
                     #     one-stream plans (another fp32 summation order)

@@ -54,7 +54,10 @@ def main():
             hit = [k for k in fetch if re.search(pat, k)]
             if not hit:
                 continue
-            k = max(hit, key=lambda k_: fetch[k_][1])          # the shape with the most launches
+            # the launch over the WHOLE batch: the largest grid that was launched a few times (the timed region runs the batch in parts --
+            # generator.split_batch -- whose launches have 1 / 4 of the grid and of the bytes; the instrumented steps run the whole batch)
+            often = [k_ for k_ in hit if fetch[k_][1] >= 3] or hit
+            k = max(often, key=lambda k_: (int(re.search(r'g=(\d+)', k_).group(1)) if re.search(r'g=(\d+)', k_) else 0, fetch[k_][1]))
             f += fetch[k][0]
             w += write.get(k, (0.0, 0))[0]
             names.append(k[:110])
