@@ -20,7 +20,7 @@ The JSON line also carries
                    `peak_sustained` is what THIS box sustains on random operands with nothing but MFMAs in flight (measured
                    live through the profiling build's lama_debug_mfma_peak: the part is power limited) and
                    `frac_of_sustained` prices the kernel against that.  `traffic` comes from the committed PMC passes
-                   (profiles/r04_pmc.json: in-pipeline counter passes; a live bench run cannot host the profiler).
+                   (profiles/r05_pmc.json: in-pipeline counter passes of this round's launch sequence; a live bench run cannot host the profiler).
   roofline_ffc  -- the unit BASELINE.json names: FourierUnit forward (rfft2 -> spectral 1x1+BN+ReLU ->
                    irfft2 + residual), algorithmic bytes / time against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (CPU restatement of the reference, same torch-CPU primitives) timed on
@@ -703,10 +703,10 @@ def main():
             roof = dict(kernel=dom, bound='mfma', achieved=round(ach, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(ach / peak, 4),
                         traffic=(pmc_traffic(dom, args.precision) or {}).get('traffic_bytes'), traffic_detail=pmc_traffic(dom, args.precision),
                         avg_us=round(kern[dom]['avg_us'], 2), flops_per_launch=flops,
-                        measured='HIP events around every launch in 3 eager steps after the timed region, on the launch stream, in the launch order of '
-                                 'the timed region (round 3: ONE stream for plans whose residual blocks take the Winograd local conv -- every kernel runs '
-                                 'alone on the GPU in the timed region too; conv1 of the next layer rides in this launch when the key says +next_conv1x1).  '
-                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r04_kernel_stats.csv',
+                        measured='HIP events around every launch in 3 eager steps of the ONE-PART plan after the timed region, on the launch stream: the launch '
+                                 'over the whole batch alone on the chip (the timed region runs the batch as parallel parts -- config.split_batch -- whose '
+                                 'quarter-size launches overlap; conv1 of the next layer rides in this launch when the key says +next_conv1x1).  '
+                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r05_kernel_stats.csv',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '
@@ -757,13 +757,15 @@ def main():
                             frac_of_6_29_TBs=round(gbs / 6290.0, 4),
                             in_sequence=None if fu not in kern_seq else dict(
                                 avg_us=round(kern_seq[fu]['avg_us'], 2),
+                                traffic=(lambda ps: sum(p_['traffic_bytes'] for p_ in ps) if all(ps) else None)(
+                                    [pmc_traffic(k, args.precision) for k in ('rfft2_192x64x64+wino_out', 'conv1x1_cin384_cout384_64x33', 'irfft2_192x64x64')]),
                                 note='the three launches as the timed region issues them: the first is rfft2_ip64_wino_out_kernel, i.e. rfft2 PLUS the '
                                      'Winograd output transform of the previous layer\'s local conv (67 MB of its own) riding in the FFT workgroups\' '
                                      'HBM-idle transform phase; avg_us above is the FourierUnit alone (plain rfft2 launch)'),
                             ceiling_three_launch=dict(bytes=three, us=round(ceil_us, 2), frac=round(alg / ceil_us / 1e3 / HBM_PEAK_GBS, 4),
                                                       note='the cap of the three-launch design itself: both fp32 spectra round-trip through '
-                                                           'memory (181 MB against 51 MB algorithmic) at 6.3 TB/s; fp16-stored spectra would '
-                                                           'lift it but cost 6-7e-4 max-abs end to end (profiles/r04_fp16_spectrum_accuracy.txt)'))
+                                                           'memory (181 MB against 51 MB algorithmic) at 6.3 TB/s; fp16-stored spectra / a 2-product GEMM would '
+                                                           'lift it but cost 5-7e-4 max-abs end to end (profiles/r05_fu_two_product_accuracy.txt)'))
             try:    # the coarser units beside it (serial-order kernel sums; MFMA utilisation is their primary figure)
                 def us(prefix):
                     ks = [k for k in kern if k.startswith(prefix)]

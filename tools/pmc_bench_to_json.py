@@ -18,17 +18,15 @@ KEYS = [   # (bench key, [kernel-name regex ...] summed, algorithmic bytes, note
      'conv1 of the next layer: x_l, t, (residual) in; x_g, x1 out; weights once'),
     ('conv3x3_cin128_cout384_64x64+1x1_cin192', [r'conv_wr_kernel_f16x3<9, 2, 1, 4, 12, 1, 0, 2, (false, ){5}2, false>'],
      MB(128, 192, 384, 384) + 2064384, 'the same launch without a next layer (the last block): x_l, t, residual in; x_g out'),
-    ('conv3x3_cin512_cout128_64x64', [r'wino_gemm_kernel', r'wino_out_kernel'], (18 * MB(512, 128, 128) + 18 * MB(512, 128)) // 36 + 2359296,
+    ('conv3x3_cin512_cout128_64x64', [r'::wino_gemm_kernel', r'::wino_out_kernel'], (18 * MB(512, 128, 128) + 18 * MB(512, 128)) // 36 + 2359296,
      'local 3x3 conv as Winograd F(2x2,3x3): both launches (residual in every second layer)'),
     ('conv1x1_cin384_cout384_64x33', [r'gemm1x1_wk_kernel'], int(2 * 4 * B * 384 * 64 * 33 + 589824), 'spectral 1x1 of the FourierUnit'),
     ('conv1x1_cin384_cout192_64x64', [r'gemm1x1_w4_kernel_f16x3<6, 2, false'], MB(384, 192) + 294912, 'SpectralTransform.conv1 as a launch of its own (first residual layer only)'),
     ('rfft2_192x64x64', [r'^void rfft2_ip64_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33), 'rfft2 of 8 x 192 planes of 64 x 64'),
-    ('rfft2_192x64x64+wino_out', [r'rfft2_ip64_wino_out_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33) + 4 * 4 * B * 128 * 64 * 64 + (18 * MB(128, 128) + 17 * MB(128)) // 35,
+    ('rfft2_192x64x64+wino_out', [r'rfft2_ip64_wino_out_kernel'], int(MB(192) + 4 * B * 384 * 64 * 33) + 2 * MB(128) + (18 * MB(128, 128) + 17 * MB(128)) // 35,
      'the FourierUnit\'s first launch AS THE TIMED REGION ISSUES IT (round 4): rfft2 of 8 x 192 planes + the Winograd output transform of the previous '
-     'layer\'s local conv riding in it (partial sums 4 x [8,128,64,64] in, residual in every second layer, y out)'),
+     'layer\'s local conv riding in it (partial sums 33.5 MB in, residual in every second layer, y out)'),
     ('irfft2_192x64x64', [r'^void irfft2_ip64_kernel'], int(2 * MB(192) + 4 * B * 384 * 64 * 33), 'irfft2 + the x + fu(x) add'),
-    ('conv3x3T_up1_up2_up3_average', [r'convt2_kernel'], int(4 * B * (512 * 64 * 64 + 256 * 128 * 128 + 256 * 128 * 128 + 128 * 256 * 256 + 128 * 256 * 256 + 64 * 512 * 512) / 3),
-     'the three ConvTranspose2d launches (one persistent grid size: the profiler cannot tell them apart): average of up1, up2, up3'),
     ('conv7x7_cin64_cout3_512x512', [r'head7_ws_kernel'], int(4 * B * 67 * 512 * 512), 'head'),
     ('conv7x7_cin4_cout64_512x512', [r'stem7_ws_kernel'], int(4 * B * 68 * 512 * 512), 'stem'),
 ]
@@ -54,10 +52,11 @@ def main():
             hit = [k for k in fetch if re.search(pat, k)]
             if not hit:
                 continue
-            # the launch over the WHOLE batch: the largest grid that was launched a few times (the timed region runs the batch in parts --
-            # generator.split_batch -- whose launches have 1 / 4 of the grid and of the bytes; the instrumented steps run the whole batch)
+            # the launch over the WHOLE batch: of the shapes launched a few times, the one that moves the most bytes (the timed region runs the batch
+            # in parts -- generator.split_batch -- whose launches move 1 / 4 of them, persistent kernels even with the same grid; the instrumented
+            # steps of bench.py run the whole batch)
             often = [k_ for k_ in hit if fetch[k_][1] >= 3] or hit
-            k = max(often, key=lambda k_: (int(re.search(r'g=(\d+)', k_).group(1)) if re.search(r'g=(\d+)', k_) else 0, fetch[k_][1]))
+            k = max(often, key=lambda k_: fetch[k_][0])
             f += fetch[k][0]
             w += write.get(k, (0.0, 0))[0]
             names.append(k[:110])

@@ -11,7 +11,7 @@
 #   quick                      bench without the cpu / f32 / eager / configs legs          -> bench_quick.json
 #   stats                      rocprofv3 --kernel-trace --stats of the quick bench         -> kernel_stats.csv, timeline.txt
 #   pmc:<kprobe names>         rocprofv3 --pmc passes (one counter set per run) over tools/kprobe.py f16x3 <names>  -> pmc_<names>/
-#   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline) -> pmc_bench/
+#   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline; LAMA_SPLIT_BATCH=1: every launch over the whole batch) -> pmc_bench_*.txt, pmc.json
 #   shapes                     the other single-GPU shapes (4x1024, 4x256, 1x512, 1x2048)
 #   kbench                     per-kernel timings, operands rotated out of the Infinity Cache (KBENCH_ROT=6)
 #   power                      MFMA sustained-rate micro-benchmark (tools/ubench/mfma_power.hip)
@@ -57,7 +57,7 @@ for STEP in "$@"; do
             rm -rf $O/prof_$N; tail -3 $O/prof_$N.log | tee -a $O/summary.txt; head -40 $O/kernel_stats_$N.csv | cut -c1-200 | tee -a $O/summary.txt ;;
     pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
     pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
-              (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
+              (cd /tmp && LAMA_SPLIT_BATCH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
               f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f > $O/pmc_bench_$CNT.txt && grep -E "conv_wr_kernel|wino_|gemm1x1_wk|fft2_ip64|convt2|head7|stem7" $O/pmc_bench_$CNT.txt | cut -c1-60,118-200 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done
               python tools/pmc_bench_to_json.py $O/pmc.json $O/pmc_bench_FETCH_SIZE.txt $O/pmc_bench_WRITE_SIZE.txt | tee -a $O/summary.txt ;;
     shapes) for cfg in "4 1024" "4 256" "1 512" "1 2048"; do set -- $cfg
