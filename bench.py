@@ -591,7 +591,7 @@ def main():
 
     # the same K steps fed from / drained to pinned HOST buffers (SURVEY.md 8(d) "includes H2D/D2H"): fp32 image + mask in, u8 out,
     # copies on the compute stream (serial, not overlapped).  Reported beside `value`, never as `value`.
-    dt_pcie = dt_piped = dt_piped_graph = dt_replay = None
+    dt_pcie = dt_piped = dt_piped_graph = dt_replay = hf_mode = None
     if world == 1:
         h_img, h_mask = img.cpu().pin_memory(), mask.cpu().pin_memory()
         h_u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8).pin_memory()
@@ -638,6 +638,7 @@ def main():
             return dt2
 
         dt_replay = host_fed('replay')
+        hf_mode = HostFedStep(model, BATCH, RES, RES, device).mode          # what `auto` (predict.py's default) picks for this shape
         dt_piped = host_fed('streams')
         dt_piped_graph = host_fed('graph')
         model.generator._plans.clear()
@@ -880,13 +881,16 @@ def main():
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
             'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg, 'batch16_leg': b16_leg,
             'value_host_fed': None if dt_replay is None else dict(
-                value=round(BATCH * args.steps / dt_replay, 3), unit='images/s', ms_per_step=round(dt_replay / args.steps * 1e3, 3),
-                vs_resident=round(dt / dt_replay, 4),
+                value=round(BATCH * args.steps / (dt_piped_graph if hf_mode == 'graph' else dt_replay), 3), unit='images/s',
+                ms_per_step=round((dt_piped_graph if hf_mode == 'graph' else dt_replay) / args.steps * 1e3, 3),
+                vs_resident=round(dt / (dt_piped_graph if hf_mode == 'graph' else dt_replay), 4), mode=hf_mode,
                 note=f'SURVEY.md 8(d) metric (i) "includes H2D/D2H": the same {args.steps} steps fed from pinned host buffers (fp32 image + mask, '
                      f'{BATCH * 4 * RES * RES * 4 / 1e6:.1f} MB in; u8 images, {BATCH * 3 * RES * RES / 1e6:.1f} MB out per step over PCIe), the way '
-                     'lama_amd.predict serves a directory: HostFedStep(mode=replay) = H2D of batch k+1 and D2H of batch k-1 on copy streams beside the '
-                     'replay of the generator\'s hipGraph for batch k; outputs equal the serial leg bit for bit.  `value` itself is the resident-input '
-                     'rate the bench contract asks for (inputs in HBM when the timed region starts).',
+                     'lama_amd.predict serves a directory: HostFedStep(mode=auto) -- H2D of batch k+1, compute of batch k, D2H of batch k-1 per launch, in '
+                     'the form `mode` names (graph: one captured hipGraph per step with the copies as branches beside the parts of the batch; replay: copy '
+                     'streams beside the replay of the generator\'s graph); outputs equal the serial leg bit for bit.  `value` itself is the '
+                     'resident-input rate the bench contract asks for (inputs in HBM when the timed region starts).',
+                copy_streams_beside_graph_replay=dict(value=round(BATCH * args.steps / dt_replay, 3), ms_per_step=round(dt_replay / args.steps * 1e3, 3)),
                 serial=dict(value=round(BATCH * args.steps / dt_pcie, 3), ms_per_step=round(dt_pcie / args.steps * 1e3, 3),
                             note='copies on the compute stream around the generator\'s own graph replay, nothing overlapped'),
                 streams_plain_launches=dict(
@@ -895,7 +899,7 @@ def main():
                 graph_with_copy_nodes=dict(
                     value=round(BATCH * args.steps / dt_piped_graph, 3), ms_per_step=round(dt_piped_graph / args.steps * 1e3, 3),
                     note='HostFedStep(mode=graph): the two copies and the compute as parallel branches of ONE captured hipGraph per step (round 5) -- '
-                         'ROCm 7.2 runs the memcpy nodes of a graph in line with its kernel nodes: no better than the serial form')),
+                         'in line with the kernels (= serial) when the compute is one kernel chain, overlapped when the batch runs in parallel parts')),
             'kernels_us': {k: round(v['avg_us'], 1) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]['total_us'])},
             'kernels_us_in_sequence': {k: round(v['avg_us'], 1) for k, v in sorted(kern_seq.items(), key=lambda kv: -kv[1]['total_us'])} if rank == 0 and kern_seq else None,
         }

@@ -190,7 +190,7 @@ class HostFedStep:
                   || compute on device set p -> u8[p]                 (THIS batch)
                   || D2H  u8[1-p] -> host result set 1-p              (the PREVIOUS batch; copy stream; ``drain``)
 
-    ``mode='replay'`` (default): the copies run on streams of their own, forked and joined by events, beside the replay of the generator's own
+    ``mode='replay'``: the copies run on streams of their own, forked and joined by events, beside the replay of the generator's own
     hipGraph (+ four plain launches: mask compose, blend, u8).  ``'streams'``: the same around ~270 plain launches.  ``'graph'``: the three as
     parallel branches INSIDE one captured hipGraph per parity (built in round 5).  Measured (bench.py value_host_fed, images/s; the boxes of
     the pool differ in GPU AND host speed; profiles/r05_host_fed.txt):
@@ -199,23 +199,31 @@ class HostFedStep:
         r4 driver (825)     761                                     788       819        --
         r05a      (800)     740                                     --        765        736
         r05b      (817)     754                                     --        740        756
+        r05h      (852)     760                                     790       531        788     (the batch in four parallel parts)
+        r05i      (837)     708                                     757       530        777     (the batch in four parallel parts)
 
     A replay of a graph overlaps copies of OTHER streams only partly (the r4 result); copy nodes INSIDE a graph run in line with its kernel
-    nodes on ROCm 7.2 (= the serial form); plain launches overlap fully but make the step launch-bound on a slow host (r05b).  'replay' is
-    the form that never loses to the serial one.
+    nodes when the graph is one kernel chain (r05a / r05b: = the serial form) but overlap when it has parallel kernel branches already
+    (r05h / r05i: the split plans of generator.split_batch -- the executor then runs the graph on several queues); plain launches overlap
+    fully but make the step launch-bound on a slow host (r05b) and with the batch in four parts.  ``mode='auto'`` (the default): 'graph'
+    where the generator splits this shape, else 'replay' -- neither ever lost to the serial form.
 
     The caller alternates p = 0, 1, 0, ...: it fills host set 1-p before ``launch(p)`` (after ``wait`` has told it that the launch that last
     read that set is complete), calls ``prime(p0)`` once before the first launch and ``flush(p_last)`` after the last.  ``drain=False``
     (multi-rank: the results go through the gather instead) leaves the D2H branch out.  On a CPU device (the emulator tests) the same body
     runs synchronously, unpinned."""
 
-    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'replay'):
+    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'auto'):
         self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
         self.drain, self.binarize = drain, binarize
-        if mode not in ('replay', 'streams', 'graph'):
-            raise L.LamaError(f'HostFedStep mode {mode!r}: replay, streams or graph')
+        if mode not in ('auto', 'replay', 'streams', 'graph'):
+            raise L.LamaError(f'HostFedStep mode {mode!r}: auto, replay, streams or graph')
+        if mode == 'auto':      # by measurement (table above): copy nodes overlap only in a graph that has parallel kernel branches already
+            gen = model.generator
+            split = gen._split_parts((self.n, 4, Hp, Wp), self.device) if hasattr(gen, '_split_parts') else 1
+            mode = 'graph' if (self.on_gpu and split > 1) else 'replay'
         self.mode = mode
         pin = dict(pin_memory=True) if self.on_gpu else {}
         self.h_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
