@@ -10,6 +10,7 @@
 #   bench[:<extra flags>]      python bench.py <flags>                                     -> bench.json (+ one-line digest)
 #   quick                      bench without the cpu / f32 / eager / configs legs          -> bench_quick.json
 #   stats                      rocprofv3 --kernel-trace --stats of the quick bench         -> kernel_stats.csv, timeline.txt
+#   overlap                    rocprofv3 kernel trace of tools/split_trace.py: which kernels ran side by side (one-part vs split plan) -> overlap_summary.txt
 #   pmc:<kprobe names>         rocprofv3 --pmc passes (one counter set per run) over tools/kprobe.py f16x3 <names>  -> pmc_<names>/
 #   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline; LAMA_SPLIT_BATCH=1: every launch over the whole batch) -> pmc_bench_*.txt, pmc.json
 #   shapes                     the other single-GPU shapes (4x1024, 4x256, 1x512, 1x2048)
@@ -48,13 +49,19 @@ for STEP in "$@"; do
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/summary.txt ;;
     bench)  timeout 1200 python bench.py $ARG > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; digest $O/bench.json | tee -a $O/summary.txt ;;
     quick)  timeout 400 python bench.py $QUICK > $O/bench_quick.json 2> $O/bench_quick.err; tail -c 300 $O/bench_quick.err; digest $O/bench_quick.json | tee -a $O/summary.txt ;;
-    stats)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
-            for db in $(find $O/prof -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats.csv; python tools/timeline.py $db $O/timeline.txt 4; done
+    stats)  # LAMA_SPLIT_BATCH=1: rocprofv3's kernel trace SERIALISES the queues a split plan runs on (profiles/r05_overlap_under_rocprof.txt: 33 ms per
+            # replay instead of 9.4), so per-kernel statistics are taken on the one-part plan -- the same kernels over the whole batch
+            (cd /tmp && LAMA_SPLIT_BATCH=1 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
+            grep -o '"value": [0-9.]*, "unit": "images/s", "n_gpus"' $O/prof_bench.log | head -1 | tee -a $O/summary.txt; grep -o '"ms_per_step": [0-9.]*' $O/prof_bench.log | head -1 | tee -a $O/summary.txt
+            for db in $(find $O/prof -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats.csv; python tools/timeline.py $db $O/timeline.txt 0; done
             rm -rf $O/prof; head -16 $O/kernel_stats.csv | cut -c1-170 | tee -a $O/summary.txt ;;
     statspy) set -- $ARG; N=$(basename $1 .py)
             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof_$N -o run -- python $ROOT/$1 ${@:2} > $ROOT/$O/prof_$N.log 2>&1)
             for db in $(find $O/prof_$N -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats_$N.csv; done
             rm -rf $O/prof_$N; tail -3 $O/prof_$N.log | tee -a $O/summary.txt; head -40 $O/kernel_stats_$N.csv | cut -c1-200 | tee -a $O/summary.txt ;;
+    overlap) (cd /tmp && timeout 600 rocprofv3 --kernel-trace -d $ROOT/$O/prof_split -o run -- python $ROOT/tools/split_trace.py 6 > $ROOT/$O/prof_split.log 2>&1)
+            for db in $(find $O/prof_split -name '*.db' | head -1); do python tools/overlap_summary.py $db 6 | tee $O/overlap_summary.txt | tee -a $O/summary.txt; done
+            rm -rf $O/prof_split; tail -2 $O/prof_split.log | tee -a $O/summary.txt ;;
     pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
     pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
               (cd /tmp && LAMA_SPLIT_BATCH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)

@@ -2,7 +2,7 @@
 """Kernel timeline of ONE bench step from a rocprofv3 --kernel-trace rocpd database: start offset, duration, queue and short kernel name of
 every dispatch between the last two stem launches -- shows which launches of the two streams really overlap (the spectral branch beside the
 local 3x3 conv) and where the main stream waits at the join.   usage: timeline.py <results.db> [out.txt] [k]
-(k: the step that ENDS at the k-th stem launch from the end, default 1; bench.py's three instrumented eager steps come last, so k = 4 is the last graph replay)"""
+(k: the step that ENDS at the k-th stem launch from the end, default 1; k = 0: the shortest step of the trace = a graph replay of the timed region)"""
 import re
 import sqlite3
 import sys
@@ -30,7 +30,11 @@ def main():
         print('# fewer than two stem launches', len(rows), file=out)
         return
     k = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-    lo, hi = stems[-k - 1], stems[-k]
+    if k == 0:      # the SHORTEST step of the trace: a hipGraph replay of the timed region (eager and host-fed steps are longer)
+        j = min(range(len(stems) - 1), key=lambda i: rows[stems[i + 1]][1] - rows[stems[i]][1])
+        lo, hi = stems[j], stems[j + 1]
+    else:
+        lo, hi = stems[-k - 1], stems[-k]
     t0 = rows[lo][1]
     prev_end = {}
     for r in rows[lo:hi]:
