@@ -303,9 +303,12 @@ class HostFedStep:
 
     # -- the caller's four verbs ----------------------------------------------------------------------------------
     def prime(self, p: int):
-        """H2D of host set p on the current stream (before the first launch of a run)."""
+        """H2D of host set p on the current stream (before the first launch of a run) and a host wait for it: the caller refills that host
+        set for the batch after next before any ``wait`` has covered this copy."""
         self.d_img[p].copy_(self.h_img[p], non_blocking=self.on_gpu)
         self.d_mask[p].copy_(self.h_mask[p], non_blocking=self.on_gpu)
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).synchronize()
 
     def launch(self, p: int):
         if not self.on_gpu:
