@@ -584,8 +584,9 @@ def main():
         model.generator.alias_wino = bool(int(os.environ['LAMA_ALIAS_WINO']))
     if 'LAMA_SPLIT_BATCH' in os.environ:      # ... of the batch as parallel branches of the graph (0 = the generator's rule, 1 = off, 2 / 4 = forced)
         model.generator.split_batch = int(os.environ['LAMA_SPLIT_BATCH']) or None
-    nsplit = model.generator._split_parts((BATCH, 4, RES, RES), device)
     dt, range_ok = timed_region(loop, args.steps, args.warmup)
+    nsplit = model.generator._split_parts((BATCH, 4, RES, RES), device)          # (after the generator's own verification of the split plan)
+    split_check = next(iter(getattr(model.generator, 'split_timing', {}).values()), None)
     if not range_ok:
         raise SystemExit('bench.py: an activation left the fp16 split\'s range during the timed steps: the run is void')
 
@@ -877,7 +878,8 @@ def main():
                                    f'mask-compose + generator + blend + u8, random-init weights',
                        'global_batch': world * BATCH, 'resolution': RES, 'parallelism': f'dp{world}',
                        'hip_graph': not args.no_graph, 'precision': args.precision,
-                       'split_batch': f'{nsplit} parts of {BATCH // nsplit} images as parallel branches of the one hipGraph (generator.split_batch)' if nsplit > 1 else 1},
+                       'split_batch': f'{nsplit} parts of {BATCH // nsplit} images as parallel branches of the one hipGraph (generator.split_batch)' if nsplit > 1 else 1,
+                       'split_check': split_check},
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
             'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg, 'batch16_leg': b16_leg,
             'value_host_fed': None if dt_replay is None else dict(

@@ -971,6 +971,13 @@ class FFCResNetGenerator(_HipModule):
         # 1 = off, 2 / 4 = forced.
         self.split_batch = None
         self.n_downsampling = n_downsampling
+        # The rule's choice is VERIFIED once per input shape (graph mode): both the split and the one-part graph are captured and replayed three
+        # times; the split plan is kept unless it is more than 3 % slower.  Parallel kernel branches are a property of the runtime: where they
+        # are serialised -- rocprofv3's kernel trace does that (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of 9.4) -- the
+        # quarter-size launches of a split plan would run one after the other on a quarter of the chip each; the check then keeps the one-part
+        # plan.  ~60 ms once per shape.  False: trust the rule.
+        self.verify_split = True
+        self._split_ok = {}               # (shape, device) -> False where the check rejected the split plan
         # False: ``forward`` returns the plan's own output buffer instead of a copy of it -- for callers that consume the result before this
         # generator's next forward of the same shape (DefaultInpaintingTrainingModule with keep_predicted_image = False: blend reads it at once)
         self.clone_output = True
@@ -990,6 +997,7 @@ class FFCResNetGenerator(_HipModule):
     def _invalidate(self):
         super()._invalidate()
         self._plans = collections.OrderedDict()
+        self._split_ok = {}
 
     def _build_plan(self, shape, device, one_stream: bool = False):
         """Pre-allocate every activation buffer for an input shape and record the launch list.  ``one_stream``: never a second stream inside this
@@ -1188,6 +1196,8 @@ class FFCResNetGenerator(_HipModule):
             n = 4 if tiles >= 256 else 1                    # 12-wave workgroup per tile and CU), so nothing splits below 256 tiles; four parts
             while n > 1 and B % n:                          # measured >= two at every size tried (profiles/r05_split_batch.txt)
                 n //= 2
+            if n > 1 and self._split_ok.get((tuple(int(v) for v in shape), str(torch.device(device)))) is False:
+                return 1                                    # this runtime does not run the parts side by side (verify_split)
             return n
         n = int(n)
         if n < 1 or n & (n - 1) or n > 4 or B % n:
@@ -1253,7 +1263,56 @@ class FFCResNetGenerator(_HipModule):
             plan['static_in'] = torch.empty(tuple(shape), device=device, dtype=torch.float32)
         return plan['static_in']
 
+    def _capture(self, plan, device):
+        """Warm the plan up on a side stream (packs weights) and capture its launches into plan['graph']; plan['static_in'] holds the input."""
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):           # warm-up outside capture
+            self._run_plan(plan, plan['static_in'])
+        torch.cuda.current_stream(device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            plan['static_out'] = self._run_plan(plan, plan['static_in'])
+        plan['graph'] = g
+
+    def tune_split(self, shape, device) -> int:
+        """``verify_split``: decide ONCE per input shape whether the split plan the rule proposes really runs its parts side by side (see
+        __init__).  Builds and captures both graphs on uniform-random input, replays each three times, keeps the winner in the plan cache and
+        returns its part count.  Host-synchronising; never called inside a stream capture."""
+        device = torch.device(device)
+        key = (tuple(int(v) for v in shape), str(device))
+        n = self._split_parts(shape, device)
+        if (n <= 1 or self.split_batch is not None or not self.verify_split or key in self._split_ok or device.type != 'cuda'
+                or torch.cuda.is_current_stream_capturing()):
+            return n
+        x = torch.rand(tuple(shape), device=device, dtype=torch.float32)
+        cand = {}
+        with self._exec.range_scope(x, self.precision, deferred=True):
+            for parts in (n, 1):
+                plan = self._build_split_plan(shape, device, parts) if parts > 1 else self._build_plan(shape, device)
+                plan['static_in'] = x
+                self._capture(plan, device)
+                plan['graph'].replay()
+                torch.cuda.synchronize(device)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
+                for _ in range(3):
+                    plan['graph'].replay()
+                t1.record()
+                torch.cuda.synchronize(device)
+                cand[parts] = (t0.elapsed_time(t1) / 3.0, plan)
+        ok = cand[n][0] <= 1.03 * cand[1][0]
+        self._split_ok[key] = ok
+        self.split_timing = {key: dict(parts=n, ms_split=round(cand[n][0], 3), ms_one_part=round(cand[1][0], 3), kept=n if ok else 1)}
+        plan = cand[n if ok else 1][1]            # (its captured graph and its input buffer -- the random tensor -- stay: forward stages into it,
+        while len(self._plans) >= max(1, self.max_plans):
+            self._plans.popitem(last=False)
+        self._plans[key] = plan                   #  input_buffer hands it to a caller that writes its input in place)
+        return n if ok else 1
+
     def _forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.use_graph and x.is_cuda and self.verify_split and self.split_batch is None:
+            self.tune_split(x.shape, x.device)
         plan = self._plan_for(x.shape, x.device)
         # ``clone_output`` False: the caller consumes the result before this generator's next forward (the plan's output buffer is returned)
         fin = (lambda t: t.clone()) if self.clone_output else (lambda t: t)
@@ -1264,15 +1323,7 @@ class FFCResNetGenerator(_HipModule):
             if not own:
                 plan['static_in'] = torch.empty_like(x)
                 plan['static_in'].copy_(x)
-            side = torch.cuda.Stream(device=x.device)
-            side.wait_stream(torch.cuda.current_stream(x.device))
-            with torch.cuda.stream(side):           # warm-up (packs weights) outside capture
-                self._run_plan(plan, plan['static_in'])
-            torch.cuda.current_stream(x.device).wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                plan['static_out'] = self._run_plan(plan, plan['static_in'])
-            plan['graph'] = g
+            self._capture(plan, x.device)
         if not own:
             plan['static_in'].copy_(x)
         plan['graph'].replay()

@@ -222,7 +222,10 @@ class HostFedStep:
             raise L.LamaError(f'HostFedStep mode {mode!r}: auto, replay, streams or graph')
         if mode == 'auto':      # by measurement (table above): copy nodes overlap only in a graph that has parallel kernel branches already
             gen = model.generator
-            split = gen._split_parts((self.n, 4, Hp, Wp), self.device) if hasattr(gen, '_split_parts') else 1
+            split = 1
+            if hasattr(gen, '_split_parts'):
+                # (the generator verifies once per shape that this runtime runs the parts side by side: FFCResNetGenerator.verify_split)
+                split = gen.tune_split((self.n, 4, Hp, Wp), self.device) if self.on_gpu else gen._split_parts((self.n, 4, Hp, Wp), self.device)
             mode = 'graph' if (self.on_gpu and split > 1) else 'replay'
         self.mode = mode
         pin = dict(pin_memory=True) if self.on_gpu else {}

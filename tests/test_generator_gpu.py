@@ -519,3 +519,40 @@ def test_split_batch_graph_is_bit_identical(big):
         gen.use_graph = False
         gen._plans.clear()
     assert gen.check_range(xd.device) is True
+
+
+def test_verify_split_keeps_the_faster_plan(big, monkeypatch):
+    """generator.verify_split: the split plan the rule proposes is timed ONCE per shape against the one-part plan and kept unless it is > 3 % slower.
+    On a runtime that runs kernel branches side by side it stays (4 parts at 8 x 512^2); where the branches are serialised (simulated here by a
+    1 ms stall at the head of every branch -- rocprofv3's kernel trace does it for real) the generator falls back to the one-part plan.  Same
+    bits either way."""
+    cfg, sd, gen, TOL = big
+    if gen.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
+        pytest.skip('the rule splits the split precisions only')
+    batch = O.make_synthetic_batch(8, 512, 512, seed=47)
+    xd = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
+    key = (tuple(xd.shape), str(xd.device))
+    try:
+        gen.use_graph = True
+        gen._plans.clear(); gen._split_ok.clear()
+        y = gen(xd).clone()
+        t = gen.split_timing[key]
+        print('verify_split:', t, flush=True)
+        assert t['parts'] == 4 and t['kept'] == 4 and gen._split_parts(xd.shape, xd.device) == 4 and gen._plans[key]['nsplit'] == 4
+        assert torch.equal(gen(xd), y)
+        # a runtime that stalls every branch: the check must reject the split plan
+        real = type(gen)._run_split
+
+        def stalled(self, plan, x):
+            torch.cuda._sleep(2_400_000)
+            return real(self, plan, x)
+
+        monkeypatch.setattr(type(gen), '_run_split', stalled)
+        gen._plans.clear(); gen._split_ok.clear()
+        y1 = gen(xd).clone()
+        t = gen.split_timing[key]
+        assert t['kept'] == 1 and gen._split_parts(xd.shape, xd.device) == 1 and 'parts' not in gen._plans[key]
+        assert torch.equal(y1, y)
+    finally:
+        gen.use_graph = False
+        gen._plans.clear(); gen._split_ok.clear()

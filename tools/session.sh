@@ -12,7 +12,7 @@
 #   stats                      rocprofv3 --kernel-trace --stats of the quick bench         -> kernel_stats.csv, timeline.txt
 #   overlap                    rocprofv3 kernel trace of tools/split_trace.py: which kernels ran side by side (one-part vs split plan) -> overlap_summary.txt
 #   pmc:<kprobe names>         rocprofv3 --pmc passes (one counter set per run) over tools/kprobe.py f16x3 <names>  -> pmc_<names>/
-#   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline; LAMA_SPLIT_BATCH=1: every launch over the whole batch) -> pmc_bench_*.txt, pmc.json
+#   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline; under the profiler the generator keeps its one-part plan: verify_split) -> pmc_bench_*.txt, pmc.json
 #   shapes                     the other single-GPU shapes (4x1024, 4x256, 1x512, 1x2048)
 #   kbench                     per-kernel timings, operands rotated out of the Infinity Cache (KBENCH_ROT=6)
 #   power                      MFMA sustained-rate micro-benchmark (tools/ubench/mfma_power.hip)
@@ -49,10 +49,10 @@ for STEP in "$@"; do
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/summary.txt ;;
     bench)  timeout 1200 python bench.py $ARG > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; digest $O/bench.json | tee -a $O/summary.txt ;;
     quick)  timeout 400 python bench.py $QUICK > $O/bench_quick.json 2> $O/bench_quick.err; tail -c 300 $O/bench_quick.err; digest $O/bench_quick.json | tee -a $O/summary.txt ;;
-    stats)  # LAMA_SPLIT_BATCH=1: rocprofv3's kernel trace SERIALISES the queues a split plan runs on (profiles/r05_overlap_under_rocprof.txt: 33 ms per
-            # replay instead of 9.4), so per-kernel statistics are taken on the one-part plan -- the same kernels over the whole batch
-            (cd /tmp && LAMA_SPLIT_BATCH=1 timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
-            grep -o '"value": [0-9.]*, "unit": "images/s", "n_gpus"' $O/prof_bench.log | head -1 | tee -a $O/summary.txt; grep -o '"ms_per_step": [0-9.]*' $O/prof_bench.log | head -1 | tee -a $O/summary.txt
+    stats)  # rocprofv3's kernel trace SERIALISES the queues a split plan runs on (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of
+            # 9.4): the generator's own check (verify_split) sees that and keeps the one-part plan -- the same kernels over the whole batch
+            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
+            grep -o '"value": [0-9.]*, "unit": "images/s", "n_gpus"' $O/prof_bench.log | head -1 | tee -a $O/summary.txt; grep -o '"ms_per_step": [0-9.]*' $O/prof_bench.log | head -1 | tee -a $O/summary.txt; grep -o '"split_batch": [^}]*}' $O/prof_bench.log | head -1 | tee -a $O/summary.txt
             for db in $(find $O/prof -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats.csv; python tools/timeline.py $db $O/timeline.txt 0; done
             rm -rf $O/prof; head -16 $O/kernel_stats.csv | cut -c1-170 | tee -a $O/summary.txt ;;
     statspy) set -- $ARG; N=$(basename $1 .py)
@@ -64,7 +64,7 @@ for STEP in "$@"; do
             rm -rf $O/prof_split; tail -2 $O/prof_split.log | tee -a $O/summary.txt ;;
     pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
     pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
-              (cd /tmp && LAMA_SPLIT_BATCH=1 timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
+              (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
               f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f > $O/pmc_bench_$CNT.txt && grep -E "conv_wr_kernel|wino_|gemm1x1_wk|fft2_ip64|convt2|head7|stem7" $O/pmc_bench_$CNT.txt | cut -c1-60,118-200 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done
               python tools/pmc_bench_to_json.py $O/pmc.json $O/pmc_bench_FETCH_SIZE.txt $O/pmc_bench_WRITE_SIZE.txt | tee -a $O/summary.txt ;;
     shapes) for cfg in "4 1024" "4 256" "1 512" "1 2048"; do set -- $cfg
