@@ -971,11 +971,11 @@ class FFCResNetGenerator(_HipModule):
         # 1 = off, 2 / 4 = forced.
         self.split_batch = None
         self.n_downsampling = n_downsampling
-        # The rule's choice is VERIFIED once per input shape (graph mode): both the split and the one-part graph are captured and replayed three
-        # times; the split plan is kept unless it is more than 3 % slower.  Parallel kernel branches are a property of the runtime: where they
+        # The rule's choice is VERIFIED once per input shape (graph mode): both the split and the one-part graph are captured and replayed alternately
+        # (best of four each); the split plan is kept unless it is more than 3 % slower.  Parallel kernel branches are a property of the runtime: where they
         # are serialised -- rocprofv3's kernel trace does that (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of 9.4) -- the
         # quarter-size launches of a split plan would run one after the other on a quarter of the chip each; the check then keeps the one-part
-        # plan.  ~60 ms once per shape.  False: trust the rule.
+        # plan.  ~100 ms once per shape.  False: trust the rule.
         self.verify_split = True
         self._split_ok = {}               # (shape, device) -> False where the check rejected the split plan
         # False: ``forward`` returns the plan's own output buffer instead of a copy of it -- for callers that consume the result before this
@@ -1277,7 +1277,7 @@ class FFCResNetGenerator(_HipModule):
 
     def tune_split(self, shape, device) -> int:
         """``verify_split``: decide ONCE per input shape whether the split plan the rule proposes really runs its parts side by side (see
-        __init__).  Builds and captures both graphs on uniform-random input, replays each three times, keeps the winner in the plan cache and
+        __init__).  Builds and captures both graphs on uniform-random input, replays them alternately (best of four each), keeps the winner in the plan cache and
         returns its part count.  Host-synchronising; never called inside a stream capture."""
         device = torch.device(device)
         key = (tuple(int(v) for v in shape), str(device))
@@ -1292,15 +1292,20 @@ class FFCResNetGenerator(_HipModule):
                 plan = self._build_split_plan(shape, device, parts) if parts > 1 else self._build_plan(shape, device)
                 plan['static_in'] = x
                 self._capture(plan, device)
-                plan['graph'].replay()
-                torch.cuda.synchronize(device)
-                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0.record()
-                for _ in range(3):
-                    plan['graph'].replay()
-                t1.record()
-                torch.cuda.synchronize(device)
-                cand[parts] = (t0.elapsed_time(t1) / 3.0, plan)
+                cand[parts] = [float('inf'), plan]
+            # alternate the two graphs (the first replays after an idle period run on ramping clocks) and keep each one's best replay
+            for rnd in range(5):
+                for parts in (n, 1):
+                    g = cand[parts][1]['graph']
+                    if rnd == 0:
+                        g.replay()                            # warm-up, untimed
+                        continue
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record()
+                    g.replay()
+                    t1.record()
+                    torch.cuda.synchronize(device)
+                    cand[parts][0] = min(cand[parts][0], t0.elapsed_time(t1))
         ok = cand[n][0] <= 1.03 * cand[1][0]
         self._split_ok[key] = ok
         self.split_timing = {key: dict(parts=n, ms_split=round(cand[n][0], 3), ms_one_part=round(cand[1][0], 3), kept=n if ok else 1)}
