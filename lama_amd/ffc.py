@@ -977,6 +977,7 @@ class FFCResNetGenerator(_HipModule):
         # quarter-size launches of a split plan would run one after the other on a quarter of the chip each; the check then keeps the one-part
         # plan.  ~100 ms once per shape.  False: trust the rule.
         self.verify_split = True
+        self._assume_graph = False        # set by a caller that captures this generator's plain launches into a graph of its own (HostFedStep)
         self._split_ok = {}               # (shape, device) -> False where the check rejected the split plan
         # False: ``forward`` returns the plan's own output buffer instead of a copy of it -- for callers that consume the result before this
         # generator's next forward of the same shape (DefaultInpaintingTrainingModule with keep_predicted_image = False: blend reads it at once)
@@ -1191,6 +1192,8 @@ class FFCResNetGenerator(_HipModule):
         if n is None:
             if torch.device(device).type != 'cuda' or self.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
                 return 1
+            if not (self.use_graph or self._assume_graph):
+                return 1                                    # plain launches: four parts are four times the host calls (launch-bound), no gain
             h, w = int(shape[2]) >> self.n_downsampling, int(shape[3]) >> self.n_downsampling
             tiles = B * ((h * w + 127) // 128)              # 128-pixel tiles of the bottleneck: the parts TOGETHER must fill the chip (one
             n = 4 if tiles >= 256 else 1                    # 12-wave workgroup per tile and CU), so nothing splits below 256 tiles; four parts

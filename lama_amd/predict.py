@@ -225,7 +225,11 @@ class HostFedStep:
             split = 1
             if hasattr(gen, '_split_parts'):
                 # (the generator verifies once per shape that this runtime runs the parts side by side: FFCResNetGenerator.verify_split)
-                split = gen.tune_split((self.n, 4, Hp, Wp), self.device) if self.on_gpu else gen._split_parts((self.n, 4, Hp, Wp), self.device)
+                keep_ag, gen._assume_graph = getattr(gen, '_assume_graph', False), True
+                try:
+                    split = gen.tune_split((self.n, 4, Hp, Wp), self.device) if self.on_gpu else 1
+                finally:
+                    gen._assume_graph = keep_ag
             mode = 'graph' if (self.on_gpu and split > 1) else 'replay'
         self.mode = mode
         pin = dict(pin_memory=True) if self.on_gpu else {}
@@ -287,8 +291,9 @@ class HostFedStep:
 
     def _capture(self, p: int):
         gen = self.model.generator
-        keep = (gen.use_graph, gen.defer_range_check)
+        keep = (gen.use_graph, gen.defer_range_check, getattr(gen, '_assume_graph', False))
         gen.use_graph, gen.defer_range_check = False, True       # the plan's launches go into THIS graph; no flag read-back (a host sync) inside it
+        gen._assume_graph = True                                 # ... so the plan may be the split one although generator.use_graph is off
         try:
             if self.graphs[1 - p] is None:                       # first capture: pack the weights / build the plan outside it
                 side = torch.cuda.Stream(device=self.device)
@@ -302,7 +307,7 @@ class HostFedStep:
                 self._body(p)
             self.graphs[p] = g
         finally:
-            gen.use_graph, gen.defer_range_check = keep
+            gen.use_graph, gen.defer_range_check, gen._assume_graph = keep
 
     # -- the caller's four verbs ----------------------------------------------------------------------------------
     def prime(self, p: int):

@@ -496,6 +496,8 @@ def test_split_batch_graph_is_bit_identical(big):
     cfg, sd, gen, TOL = big
     batch = O.make_synthetic_batch(8, 512, 512, seed=43)
     xd = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
+    assert gen._split_parts(xd.shape, xd.device) == 1                       # plain launches: never split
+    gen.use_graph = True
     auto = gen._split_parts(xd.shape, xd.device)
     assert auto == (4 if gen.precision in (L.PREC_F16X3, L.PREC_BF16X3) else 1)
     assert gen._split_parts((4, 4, 1024, 1024), xd.device) == auto and gen._split_parts((4, 4, 512, 512), xd.device) == 1
