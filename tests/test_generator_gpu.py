@@ -526,7 +526,7 @@ def test_split_batch_graph_is_bit_identical(big):
 def test_verify_split_keeps_the_faster_plan(big, monkeypatch):
     """generator.verify_split: the split plan the rule proposes is timed ONCE per shape against the one-part plan and kept unless it is > 25 % slower.
     On a runtime that runs kernel branches side by side it stays (4 parts at 8 x 512^2); where the branches are serialised (simulated here by a
-    1 ms stall at the head of every branch -- rocprofv3's kernel trace does it for real) the generator falls back to the one-part plan.  Same
+    5 ms stall at the head of the branches -- rocprofv3's kernel trace does it for real) the generator falls back to the one-part plan.  Same
     bits either way."""
     cfg, sd, gen, TOL = big
     if gen.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
@@ -546,7 +546,7 @@ def test_verify_split_keeps_the_faster_plan(big, monkeypatch):
         real = type(gen)._run_split
 
         def stalled(self, plan, x):
-            torch.cuda._sleep(2_400_000)
+            torch.cuda._sleep(12_000_000)
             return real(self, plan, x)
 
         monkeypatch.setattr(type(gen), '_run_split', stalled)
