@@ -972,8 +972,7 @@ class FFCResNetGenerator(_HipModule):
         self.split_batch = None
         self.n_downsampling = n_downsampling
         # The rule's choice is VERIFIED once per input shape (graph mode): both the split and the one-part graph are captured and replayed alternately
-        # (best of four each); the split plan is kept unless it is more than 25 % slower (serialised branches cost 2.5x; isolated replays are no
-        # basis for decisions of a few per cent: they once rejected the 16-image split that is 4 % faster in a steady loop).  Parallel kernel branches are a property of the runtime: where they
+        # (best of four each); the split plan is kept only if it is not slower.  Parallel kernel branches are a property of the runtime: where they
         # are serialised -- rocprofv3's kernel trace does that (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of 9.4) -- the
         # quarter-size launches of a split plan would run one after the other on a quarter of the chip each; the check then keeps the one-part
         # plan.  ~100 ms once per shape.  False: trust the rule.
@@ -1310,7 +1309,7 @@ class FFCResNetGenerator(_HipModule):
                     t1.record()
                     torch.cuda.synchronize(device)
                     cand[parts][0] = min(cand[parts][0], t0.elapsed_time(t1))
-        ok = cand[n][0] <= 1.25 * cand[1][0]         # a serialisation detector, not a tuner: isolated replays misjudge a few per cent either way
+        ok = cand[n][0] <= cand[1][0]
         self._split_ok[key] = ok
         self.split_timing = {key: dict(parts=n, ms_split=round(cand[n][0], 3), ms_one_part=round(cand[1][0], 3), kept=n if ok else 1)}
         plan = cand[n if ok else 1][1]            # (its captured graph and its input buffer -- the random tensor -- stay: forward stages into it,

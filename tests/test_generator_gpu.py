@@ -524,7 +524,7 @@ def test_split_batch_graph_is_bit_identical(big):
 
 
 def test_verify_split_keeps_the_faster_plan(big, monkeypatch):
-    """generator.verify_split: the split plan the rule proposes is timed ONCE per shape against the one-part plan and kept unless it is > 25 % slower.
+    """generator.verify_split: the split plan the rule proposes is timed ONCE per shape against the one-part plan and kept only if it is not slower.
     On a runtime that runs kernel branches side by side it stays (4 parts at 8 x 512^2); where the branches are serialised (simulated here by a
     5 ms stall at the head of the branches -- rocprofv3's kernel trace does it for real) the generator falls back to the one-part plan.  Same
     bits either way."""
