@@ -498,6 +498,7 @@ def test_split_batch_graph_is_bit_identical(big):
     xd = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1).cuda()
     assert gen._split_parts(xd.shape, xd.device) == 1                       # plain launches: never split
     gen.use_graph = True
+    gen._split_ok.clear()                                                    # (an earlier test's verify_split verdict on this box: the RULE is asserted here)
     auto = gen._split_parts(xd.shape, xd.device)
     assert auto == (4 if gen.precision in (L.PREC_F16X3, L.PREC_BF16X3) else 1)
     assert gen._split_parts((4, 4, 1024, 1024), xd.device) == auto and gen._split_parts((4, 4, 512, 512), xd.device) == 1
@@ -525,9 +526,9 @@ def test_split_batch_graph_is_bit_identical(big):
 
 def test_verify_split_keeps_the_faster_plan(big, monkeypatch):
     """generator.verify_split: the split plan the rule proposes is timed ONCE per shape against the one-part plan and kept only if it is not slower.
-    On a runtime that runs kernel branches side by side it stays (4 parts at 8 x 512^2); where the branches are serialised (simulated here by a
-    5 ms stall at the head of the branches -- rocprofv3's kernel trace does it for real) the generator falls back to the one-part plan.  Same
-    bits either way."""
+    On a runtime that runs kernel branches side by side the two are within a few per cent and the faster one stays (the split plan on most
+    boxes); where the branches are serialised (simulated here by a 5 ms stall at the head of the branches -- rocprofv3's kernel trace does it
+    for real) the generator falls back to the one-part plan.  Same bits either way."""
     cfg, sd, gen, TOL = big
     if gen.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
         pytest.skip('the rule splits the split precisions only')
@@ -540,7 +541,10 @@ def test_verify_split_keeps_the_faster_plan(big, monkeypatch):
         y = gen(xd).clone()
         t = gen.split_timing[key]
         print('verify_split:', t, flush=True)
-        assert t['parts'] == 4 and t['kept'] == 4 and gen._split_parts(xd.shape, xd.device) == 4 and gen._plans[key]['nsplit'] == 4
+        # whichever plan was faster in this process stays (the split one on most boxes: +2.4 ... +5 %; the one-part one where the parts lost by a per cent)
+        assert t['parts'] == 4 and t['kept'] == (4 if t['ms_split'] <= t['ms_one_part'] else 1)
+        assert gen._split_parts(xd.shape, xd.device) == t['kept'] and gen._plans[key].get('nsplit', 1) == t['kept']
+        assert t['ms_split'] < 1.15 * t['ms_one_part'], t          # ... and on a healthy runtime the two are within a few per cent
         assert torch.equal(gen(xd), y)
         # a runtime that stalls every branch: the check must reject the split plan
         real = type(gen)._run_split
