@@ -967,7 +967,7 @@ class FFCResNetGenerator(_HipModule):
         # side by side on ROCm 7.2; two graphs do not) put one part's memory-bound launches beside the other's MFMA-bound ones and fill each
         # other's boundaries: 8 x 512^2 +3-5 %, 4 x 1024^2 +7-8 %, 16 x 512^2 in four parts +18 % (same box, bit-identical output:
         # profiles/r05_split_batch.txt).  Each part's launches tell the library that they share the chip (LAMA_CONV_SIBLINGS_*, v109) and get the
-        # kernel geometry of the whole batch.  None = by shape (_split_parts: GPU, split precisions, from 256 bottleneck tiles on: four parts, two when 4 does not divide the batch),
+        # kernel geometry of the whole batch.  None = by shape (_split_parts: GPU, graph mode, every precision but exact fp32, from 256 bottleneck tiles on: four parts, two when 4 does not divide the batch),
         # 1 = off, 2 / 4 = forced.
         self.split_batch = None
         self.n_downsampling = n_downsampling
@@ -1190,7 +1190,7 @@ class FFCResNetGenerator(_HipModule):
         B = int(shape[0])
         n = self.split_batch
         if n is None:
-            if torch.device(device).type != 'cuda' or self.precision not in (L.PREC_F16X3, L.PREC_BF16X3):
+            if torch.device(device).type != 'cuda' or self.precision not in (L.PREC_F16X3, L.PREC_BF16X3, L.PREC_F16):
                 return 1
             if not (self.use_graph or self._assume_graph):
                 return 1                                    # plain launches: four parts are four times the host calls (launch-bound), no gain

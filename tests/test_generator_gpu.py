@@ -280,6 +280,12 @@ def test_biglama_fp16_activation_path(shape):
     gen.use_graph = True
     yg = gen(xd)
     assert torch.equal(gen(xd), yg) and torch.equal(yg, y)
+    if (bn, res) == (4, 1024):      # round 5: the graph of this shape is four parallel parts (or the one-part plan where verify_split found that faster)
+        plan = next(iter(gen._plans.values()))
+        assert gen._split_parts(xd.shape, xd.device) == plan.get('nsplit', 1) and plan.get('nsplit', 1) in (1, 4)
+        gen.split_batch = 4          # ... and forced: the same bits as the eager one-part plan above
+        gen._plans.clear()
+        assert torch.equal(gen(xd), y)
     gen._plans.clear()
 
 
