@@ -21,8 +21,6 @@ LIB = os.path.join(LIBDIR, 'liblama_hip.so')
 # Only tools/ and the forced-path GPU tests load it (tools/_toollib.py, bench.py --lib, LamaLib(path)); the product never does.
 LIB_PROF = os.path.join(LIBDIR, 'liblama_hip_prof.so')
 SOURCES = ['conv_mfma.hip', 'conv_bf16x3.hip', 'conv_f16x3.hip', 'conv_f16.hip', 'fft.hip', 'elementwise.hip', 'refine.hip', 'metrics.hip']
-HEADERS = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'gemm_wk_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'), os.path.join(CSRC, 'wino_dev.inc'), os.path.join(CSRC, 'convt_dev.inc'),
-           os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h')]
 # Every translation unit is compiled WITHOUT packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).
 # Measured on MI355X / ROCm 7.2 (the probes -- tools/race_probe1-9.py, overlap_stress.py -- are in the git history): a v_pk_*_f32 with an op_sel half-swizzle returns wrong
 # results while a wave of ANOTHER kernel executes MFMA instructions on the same SIMD (an inline-asm probe of that one instruction
@@ -65,22 +63,50 @@ for _s in SOURCES:
     PER_SOURCE_FLAGS[_s] = NO_PACKED_FP32
 
 
+def _include_closure(path, seen=None):
+    """The file and every `#include "..."` it reaches under csrc/ or include/ (what an object file really depends on)."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen:
+        return seen
+    seen.add(path)
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), re.M):
+        for base in (os.path.dirname(path), CSRC, os.path.join(ROOT, 'include')):
+            cand = os.path.join(base, name)
+            if os.path.exists(cand):
+                _include_closure(cand, seen)
+                break
+    return seen
+
+
 def _build_one(lib: str, extra_flags, force: bool, verbose: bool, extra_sources=()) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in list(SOURCES) + list(extra_sources)]
     tag = os.path.splitext(os.path.basename(lib))[0]
     stamp = os.path.join(LIBDIR, tag + '.sha256')
-    dig = _digest(srcs + HEADERS, extra_flags)
+    dig = _digest(sorted(set().union(*[_include_closure(s) for s in srcs])), extra_flags)   # every file any source includes: no list to maintain
     if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return lib
     hipcc = _hipcc()
     objdir = os.path.join(LIBDIR, 'obj', tag)
     os.makedirs(objdir, exist_ok=True)
-    jobs = [(s, os.path.join(objdir, os.path.basename(s) + '.o'), hipcc, extra_flags) for s in srcs]
+    # per-object stamps over the include closure of each source: an edit recompiles only the translation units that see it
+    jobs, objs, stamps = [], [], {}
+    for s in srcs:
+        o = os.path.join(objdir, os.path.basename(s) + '.o')
+        odig = _digest(sorted(_include_closure(s)), extra_flags)
+        objs.append(o)
+        if force or not (os.path.exists(o) and os.path.exists(o + '.sha256') and open(o + '.sha256').read().strip() == odig):
+            jobs.append((s, o, hipcc, extra_flags))
+            stamps[o] = odig
     if verbose:
-        print(f'[lama_amd.build] hipcc {len(jobs)} sources for gfx950 -> {os.path.basename(lib)} ...', file=sys.stderr)
-    with concurrent.futures.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
-        objs = list(ex.map(_compile, jobs))
+        print(f'[lama_amd.build] hipcc {len(jobs)} of {len(srcs)} sources for gfx950 -> {os.path.basename(lib)} ...', file=sys.stderr)
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+            list(ex.map(_compile, jobs))
+    for o, d in stamps.items():
+        with open(o + '.sha256', 'w') as f:
+            f.write(d)
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')

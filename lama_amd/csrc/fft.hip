@@ -1664,6 +1664,8 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void fq_rows_inv_kernel(FftParams p,
     }
 }
 
+#include "fft_mr_dev.inc"
+
 // ------------------------------------------------------------------------------------------------
 namespace {
 
@@ -1727,6 +1729,80 @@ long long* fft_trace_buf() {
 bool fft_inplace() {
     return lama_env_int("LAMA_FFT_INPLACE", 1) != 0;   // a constant in the product build
 }
+
+// mixed-radix plane-in-LDS kernels (fft_mr_dev.inc): the pass list of one length.  Butterflies in registers exist for the radices of
+// mr_radices (composites up to 16 as one Cooley-Tukey step with constant twiddles, primes up to 13); the fewest passes win, ties go to the
+// list with the larger smallest radix.  Whatever is left of n (prime factors > 13) becomes thread-per-output passes.  -1: does not fit.
+const int mr_radices[] = {16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2, 11, 13};
+int mr_plan_smooth(int n, unsigned short* rad, int depth) {      // n = product of listed radices, or -1
+    if (n == 1) return 0;
+    if (depth >= MR_MAXP) return -1;
+    int best = -1, best_min = 0;
+    unsigned short tmp[MR_MAXP];
+    for (int r : mr_radices) {
+        if (n % r) continue;
+        const int np = mr_plan_smooth(n / r, tmp + 1, depth + 1);
+        if (np < 0) continue;
+        tmp[0] = (unsigned short)r;
+        int mn = r;
+        for (int i = 1; i <= np; ++i) mn = tmp[i] < mn ? tmp[i] : mn;
+        if (best < 0 || np + 1 < best || (np + 1 == best && mn > best_min)) {
+            best = np + 1;
+            best_min = mn;
+            for (int i = 0; i <= np; ++i) rad[i] = tmp[i];
+        }
+    }
+    return best;
+}
+int mr_plan(int n, unsigned short* rad) {
+    int np = 0, rest = 1, m = n;
+    for (int p = 2; p <= 13; ++p) while (m % p == 0) { m /= p; rest *= p; }      // rest: the part the register butterflies take
+    for (int p = 17; m > 1 && p <= 65535 && np < MR_MAXP; p += 2) while (m % p == 0 && np < MR_MAXP) { rad[np++] = (unsigned short)p; m /= p; }
+    if (m != 1) return -1;
+    if (rest > 1) {
+        const int ns = mr_plan_smooth(rest, rad + np, np);
+        if (ns < 0) return -1;
+        np += ns;
+    }
+    return np;
+}
+// threads per workgroup (256, or 512 for planes of more than 5120 elements: two waves per SIMD with a 256-register budget each; 0 = the plane does not fit) and the LDS bytes of the one-pass mixed-radix kernels
+int mr_threads(int h, int w, size_t* lds) {
+#ifdef LAMA_PROFILING
+    static const int on = lama_env_int("LAMA_FFT_MR", 1);
+    if (!on) return 0;
+#endif
+    if (h < 1 || w < 2 || h > 65535 || w > 65535) return 0;
+    const long long hh = (h + 1) / 2, wf = w / 2 + 1, rsw = w | 1;
+    const long long elems = hh * rsw > (long long)h * wf ? hh * rsw : (long long)h * wf;
+    const long long bytes = (elems + w + h) * (long long)sizeof(float2);
+    if (bytes > 160 * 1024) return 0;
+    *lds = (size_t)bytes;
+    for (int nt = 256; nt <= 512; nt *= 2)
+        if (elems <= (long long)nt * MR_MAXE_OF(nt) && hh * wf <= (long long)nt * (MR_MAXE_OF(nt) / 2)) return nt;
+    return 0;
+}
+bool mr_fill(MrParams& q, const FftParams& p, int nt) {
+    q.f = p;
+    q.rsw = p.w | 1;
+    q.nrp = mr_plan(p.w, q.rrad);
+    q.ncp = mr_plan(p.h, q.crad);
+    if (q.nrp < 0 || q.ncp < 0) return false;
+    // a thread-per-output pass (prime factor > 7) walks the transforms in groups of nt * MR_ANYE / N: at least one must fit
+    // (a register pass walks chunks of MAXIT * nt / (N / R) transforms -- MAXIT >= 1: the same bound covers it)
+    for (int i = 0; i < q.nrp; ++i) if ((q.rrad[i] > 16 ? p.w : p.w / q.rrad[i]) > nt * (q.rrad[i] > 16 ? MR_ANYE : 1)) return false;
+    for (int i = 0; i < q.ncp; ++i) if ((q.crad[i] > 16 ? p.h : p.h / q.crad[i]) > nt * (q.crad[i] > 16 ? MR_ANYE : 1)) return false;
+    return true;
+}
+#ifdef MR_BENCH_ONLY      // tools/ubench/mk_mr_bench.sh: one instantiation per kernel (compile time of the ablation builds)
+#define MR_GO(name, nt, lds, q) hipLaunchKernelGGL((name<MR_BENCH_ONLY, false>), dim3((q).f.nplanes), dim3(MR_BENCH_ONLY), lds, st, q)
+#else
+#define MR_GO(name, nt, lds, q)                                                                     \
+    do {                                                                                            \
+        if (nt == 256) FFT_GO(name, (256), dim3((q).f.nplanes), dim3(256), lds, q);                 \
+        else FFT_GO(name, (512), dim3((q).f.nplanes), dim3(512), lds, q);                         \
+    } while (0)
+#endif
 
 bool fft_args_ok(const lama_tensor* real, const lama_tensor* spec, int batch) {
     if (!real || !spec || !real->ptr || !spec->ptr || batch <= 0) return false;
@@ -1811,10 +1887,24 @@ static int rfft2_impl(void* stream, const lama_tensor* x, const lama_tensor* spe
         return LAMA_OK;
     }
     if (wo) return LAMA_ERR_UNSUPPORTED;
+    const bool fq = fq_ok(p.h, p.w, hf) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4) | (uintptr_t)workspace) & 15) == 0;
+    if (!mask && !(fq && workspace)) {   // any plane that fits one workgroup's LDS: the mixed-radix one-pass kernel (no workspace)
+        size_t lds = 0;
+        MrParams q;
+        const int nt = mr_threads(p.h, p.w, &lds);
+        if (nt && mr_fill(q, p, nt)) {
+#ifdef MR_TRACE
+            q.f.trace = fft_trace_buf();
+#endif
+            MR_GO(rfft2_mr_kernel, nt, lds, q);
+            LAMA_CHECK_LAUNCH();
+            return LAMA_OK;
+        }
+    }
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
-    if (fq_ok(p.h, p.w, hf) && (((uintptr_t)x->ptr | (uintptr_t)(x->batch_stride * 4) | (uintptr_t)workspace) & 15) == 0) {
+    if (fq) {
         hipLaunchKernelGGL(fq_rows_fwd_kernel, dim3(p.nplanes * (FQ_N / 2 / FQ_PAIRS)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_PAIRS * (FQ_N + 1)) * sizeof(float2), st, p, ws);
         LAMA_CHECK_LAUNCH();
         hipLaunchKernelGGL(fq_cols_kernel<false>, dim3(p.nplanes * (FQ_N / 2 / FQ_CW)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_N * FQ_CP) * sizeof(float2), st, p, ws);
@@ -1902,10 +1992,21 @@ static int irfft2_impl(void* stream, const lama_tensor* spec, const lama_tensor*
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
+    const bool fq = fq_ok(p.h, p.w, hf) && ((al | (uintptr_t)workspace) & 15) == 0;
+    if (!mask && !(fq && workspace)) {
+        size_t lds = 0;
+        MrParams q;
+        const int nt = mr_threads(p.h, p.w, &lds);
+        if (nt && mr_fill(q, p, nt)) {
+            MR_GO(irfft2_mr_kernel, nt, lds, q);
+            LAMA_CHECK_LAUNCH();
+            return LAMA_OK;
+        }
+    }
     size_t need = (size_t)p.nplanes * p.h * p.wf * sizeof(float2);
     if (!workspace || workspace_bytes < need) return LAMA_ERR_WORKSPACE;
     float2* ws = (float2*)workspace;
-    if (fq_ok(p.h, p.w, hf) && ((al | (uintptr_t)workspace) & 15) == 0) {
+    if (fq) {
         hipLaunchKernelGGL(fq_cols_kernel<true>, dim3(p.nplanes * (FQ_N / 2 / FQ_CW)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_N * FQ_CP) * sizeof(float2), st, p, ws);
         LAMA_CHECK_LAUNCH();
         hipLaunchKernelGGL(fq_rows_inv_kernel, dim3(p.nplanes * (FQ_N / 2 / FQ_PAIRS)), dim3(LAMA_NTHREADS), (size_t)(FQ_N + FQ_PAIRS * (FQ_N + 1)) * sizeof(float2), st, p, (const float2*)ws);

@@ -28,7 +28,7 @@ def build(force=False):
 
 def _build(force):
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip') and f != 'debug_probes.hip')
-    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'gemm_wk_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'), os.path.join(CSRC, 'wino_dev.inc'), os.path.join(CSRC, 'convt_dev.inc'),
+    deps = srcs + [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'conv_split3.inc'), os.path.join(CSRC, 'conv_wreg_dev.inc'), os.path.join(CSRC, 'conv_ws_dev.inc'), os.path.join(CSRC, 'gemm_wk_dev.inc'), os.path.join(CSRC, 'conv_stem_dev.inc'), os.path.join(CSRC, 'conv_head_dev.inc'), os.path.join(CSRC, 'wino_dev.inc'), os.path.join(CSRC, 'convt_dev.inc'), os.path.join(CSRC, 'wino_out_dev.inc'), os.path.join(CSRC, 'fft_mr_dev.inc'),
                    os.path.join(CSRC, 'conv_wreg_host.inc'), os.path.join(ROOT, 'include', 'lama_hip.h'),
                    os.path.join(HERE, 'hip', 'hip_runtime.h'), os.path.join(HERE, 'hipemu_runtime.cpp')]
     h = hashlib.sha256()

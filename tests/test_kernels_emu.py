@@ -195,8 +195,10 @@ def _inv_ref(spec, h, w):
 
 
 FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32), (128, 128),   # fused LDS path (64 / 128 squares: one-buffer kernels)
-             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13),          # generic DFT path (one Cooley-Tukey split; primes: direct)
-             (45, 60), (21, 94), (27, 25),                                    # ... 9x5 / 6x10, 3x7 / 2x47, 3x9 / 5x5
+             (8, 12), (5, 9), (10, 7), (24, 40), (17, 16), (13, 13),          # round 6: mixed-radix plane-in-LDS kernels (fft_mr_dev.inc): radix 2 / 3 / 4 / 5 / 7 / 8
+             (45, 60), (21, 94), (27, 25),                                    # ... 9x5 / 4x3x5, 3x7 / 2x47 (thread-per-output pass of a prime), 3x3x3 / 5x5
+             (9, 14), (35, 30), (22, 26), (1, 16), (3, 2), (49, 56), (67, 40),  # ... 7x2, 5x7 / 2x3x5, primes 11 / 13, degenerate planes, 7x7 / 8x7, a prime height
+             (90, 160),                                                       # ... the bottleneck plane of a 720 x 1280 frame (512 threads)
              (256, 32), (16, 512), (256, 256)]                                # two-pass LDS path
 
 
@@ -325,7 +327,7 @@ def test_c_abi_rejects_bad_arguments():
     with pytest.raises(L.LamaError):
         lib.rfft2(L.view(x), L.view(torch.zeros(1, 8, 8, 4)), 1)      # wrong spectrum width
     with pytest.raises(L.LamaError):
-        lib.rfft2(L.view(torch.zeros(1, 4, 10, 12)), L.view(torch.zeros(1, 8, 10, 7)), 1, None)   # missing workspace
+        lib.rfft2(L.view(torch.zeros(1, 4, 192, 256)), L.view(torch.zeros(1, 8, 192, 129)), 1, None)   # missing workspace (a plane too large for one workgroup's LDS: two launches)
 
 
 def test_f16_split_range_watch_emulated():
