@@ -525,6 +525,7 @@ def main():
     ap.add_argument('--precision', default=os.environ.get('LAMA_PRECISION', 'f16x3'), choices=['f32', 'bf16x3', 'f16x3'])
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the extra exact-fp32 timing leg')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--split-batch', type=int, default=0, choices=[0, 1, 2, 4], help='parts of the batch as parallel branches of the hipGraph: 0 = the generator\'s rule, verified by timing once per shape (config.split_check); 1 / 2 / 4 force it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the PyTorch-ROCm eager comparator (subprocess)')
     ap.add_argument('--lib', default=None, help='A/B runs: another build of liblama_hip.so (e.g. lama_amd/lib/liblama_hip_prof.so, whose kernel '
@@ -584,9 +585,11 @@ def main():
         model.generator.alias_wino = bool(int(os.environ['LAMA_ALIAS_WINO']))
     if 'LAMA_SPLIT_BATCH' in os.environ:      # ... of the batch as parallel branches of the graph (0 = the generator's rule, 1 = off, 2 / 4 = forced)
         model.generator.split_batch = int(os.environ['LAMA_SPLIT_BATCH']) or None
+    if args.split_batch:                      # --split-batch 1|2|4: override the generator's rule and its timing check
+        model.generator.split_batch = args.split_batch
     dt, range_ok = timed_region(loop, args.steps, args.warmup)
     nsplit = model.generator._split_parts((BATCH, 4, RES, RES), device)          # (after the generator's own verification of the split plan)
-    split_check = next(iter(getattr(model.generator, 'split_timing', {}).values()), None)
+    split_check = {f'{k[0][0]}x{k[0][2]}x{k[0][3]}': v for k, v in getattr(model.generator, 'split_decisions', {}).items()} or None   # every shape tune_split decided in this process
     if not range_ok:
         raise SystemExit('bench.py: an activation left the fp16 split\'s range during the timed steps: the run is void')
 

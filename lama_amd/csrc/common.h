@@ -56,6 +56,12 @@ __device__ __forceinline__ int lama_xcd_remap(int orig, int nwg) {
 #define LAMA_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #endif
 
+// address space of LDS in pointer TYPES (device functions that are not inlined lose the inference: flat instead of ds instructions).
+// (tests/hipemu defines it away.)
+#ifndef LAMA_LDS_AS
+#define LAMA_LDS_AS __attribute__((address_space(3)))
+#endif
+
 // keep a value live without cost (timing ablations must not let the compiler delete the work that produced it)
 #ifndef LAMA_KEEP_LIVE
 #define LAMA_KEEP_LIVE(x) asm volatile("" ::"v"(x))

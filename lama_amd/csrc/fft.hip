@@ -1766,7 +1766,7 @@ int mr_plan(int n, unsigned short* rad) {
     }
     return np;
 }
-// threads per workgroup (256, or 512 for planes of more than 5120 elements: two waves per SIMD with a 256-register budget each; 0 = the plane does not fit) and the LDS bytes of the one-pass mixed-radix kernels
+// threads per workgroup (256, or 1024 for planes of more than 5120 elements -- four waves per SIMD at 128 registers measured a little faster than 512 threads at 256, spills of the radix-14 .. 16 passes included: profiles/r06_fft_mr.txt; 0 = the plane does not fit) and the LDS bytes of the one-pass mixed-radix kernels
 int mr_threads(int h, int w, size_t* lds) {
 #ifdef LAMA_PROFILING
     static const int on = lama_env_int("LAMA_FFT_MR", 1);
@@ -1778,7 +1778,7 @@ int mr_threads(int h, int w, size_t* lds) {
     const long long bytes = (elems + w + h) * (long long)sizeof(float2);
     if (bytes > 160 * 1024) return 0;
     *lds = (size_t)bytes;
-    for (int nt = 256; nt <= 512; nt *= 2)
+    for (int nt = 256; nt <= 1024; nt *= 4)
         if (elems <= (long long)nt * MR_MAXE_OF(nt) && hh * wf <= (long long)nt * (MR_MAXE_OF(nt) / 2)) return nt;
     return 0;
 }
@@ -1800,7 +1800,7 @@ bool mr_fill(MrParams& q, const FftParams& p, int nt) {
 #define MR_GO(name, nt, lds, q)                                                                     \
     do {                                                                                            \
         if (nt == 256) FFT_GO(name, (256), dim3((q).f.nplanes), dim3(256), lds, q);                 \
-        else FFT_GO(name, (512), dim3((q).f.nplanes), dim3(512), lds, q);                         \
+        else FFT_GO(name, (1024), dim3((q).f.nplanes), dim3(1024), lds, q);                         \
     } while (0)
 #endif
 

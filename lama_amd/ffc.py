@@ -123,6 +123,7 @@ class _Exec:
         self.injected = lib is not None
         self._flags = {}                  # one flag per DEVICE of this exec -- shared by every generator that runs on it (the default exec: all of them)
         self._deferred_since_read = {}    # device -> deferred scopes have run since the flag was last read
+        self._sticky = {}                 # device -> a deferred report a self-checking scope had to clear from the device flag (kept for check_range)
         self._depth = 0
         self.no_fuse1 = set()      # (input shape, precision) at which the fused conv1 epilogue was refused (FFC.launch)
         self._cur_flag = None
@@ -159,8 +160,11 @@ class _Exec:
             if key not in self._flags:
                 self._flags[key] = torch.zeros(1, dtype=torch.int32, device=t.device)
             elif not deferred and self._deferred_since_read.get(key):
-                # a flag left raised by DEFERRED forwards nobody asked about (check_range) is not this forward's: a self-checking forward starts
-                # from a clean flag (an asynchronous 4-byte memset on the launch stream -- no host synchronisation)
+                # a flag left raised by DEFERRED forwards nobody asked about yet (check_range) is not this forward's: a self-checking forward starts
+                # from a clean flag -- but the report is not lost: it is read here (this scope synchronises at its end anyway) and kept
+                # as a host-side sticky bit that the next check_range / range_flag_raised ORs in
+                if int(self._flags[key].item()) != 0:
+                    self._sticky[key] = True
                 self._flags[key].zero_()
             self._deferred_since_read[key] = bool(deferred)
             self._cur_flag = self._flags[key]
@@ -191,7 +195,26 @@ class _Exec:
             if int(flag.item()) != 0:
                 flag.zero_()
                 bad = True
+            if self._sticky.pop(key, False):
+                bad = True
         return bad
+
+    @contextlib.contextmanager
+    def scratch_range_scope(self, t: torch.Tensor, precision: int):
+        """Forwards whose VALUES do not matter (tune_split times graphs on noise): whatever they raise is discarded, and a report that deferred
+        forwards of the caller left pending before is preserved (read first, restored afterwards).  Host-synchronising."""
+        key = self._dev_key(t.device)
+        flag = self._flags.get(key)
+        pending = bool(self._deferred_since_read.get(key))
+        was = flag is not None and pending and int(flag.item()) != 0
+        try:
+            with self.range_scope(t, precision, deferred=True):
+                yield
+        finally:
+            flag = self._flags.get(key)
+            if flag is not None:
+                flag.fill_(1 if was else 0)
+            self._deferred_since_read[key] = pending
 
     @staticmethod
     def _dev_key(device) -> str:
@@ -972,13 +995,17 @@ class FFCResNetGenerator(_HipModule):
         self.split_batch = None
         self.n_downsampling = n_downsampling
         # The rule's choice is VERIFIED once per input shape (graph mode): both the split and the one-part graph are captured and replayed alternately
-        # (best of four each); the split plan is kept only if it is not slower.  Parallel kernel branches are a property of the runtime: where they
+        # (median of 9 each); the split plan is kept only if it is at least 2 % faster (split_margin; a tie keeps the one-part plan, so the decision is
+        # the same from process to process) and the loser's buffers are released at once.  Parallel kernel branches are a property of the runtime: where they
         # are serialised -- rocprofv3's kernel trace does that (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of 9.4) -- the
         # quarter-size launches of a split plan would run one after the other on a quarter of the chip each; the check then keeps the one-part
         # plan.  ~100 ms once per shape.  False: trust the rule.
         self.verify_split = True
         self._assume_graph = False        # set by a caller that captures this generator's plain launches into a graph of its own (HostFedStep)
         self._split_ok = {}               # (shape, device) -> False where the check rejected the split plan
+        self.split_decisions = {}         # (shape, device) -> what tune_split measured and kept (bench.py prints it)
+        self.split_margin = 0.02          # the split plan must be this much faster (median) to be kept
+        self.split_replays = 9            # timed replays of each graph in tune_split
         # False: ``forward`` returns the plan's own output buffer instead of a copy of it -- for callers that consume the result before this
         # generator's next forward of the same shape (DefaultInpaintingTrainingModule with keep_predicted_image = False: blend reads it at once)
         self.clone_output = True
@@ -1153,7 +1180,13 @@ class FFCResNetGenerator(_HipModule):
 
     def drop_plan(self, shape, device) -> None:
         """Free the activation buffers / captured graph of one input shape (predict.py drops a bucket's plan when it is done)."""
-        self._plans.pop((tuple(shape), str(torch.device(device))), None)
+        self._plans.pop(self._plan_key(shape, device), None)
+
+    @staticmethod
+    def _plan_key(shape, device):
+        """Key of the plan cache and of the split verdicts: 'cuda' and 'cuda:<current>' are ONE device (predict / HostFedStep pass
+        torch.device('cuda'), every forward sees x.device = 'cuda:0' -- two keys meant a verdict and a tuned plan no forward ever found)."""
+        return (tuple(int(v) for v in shape), _Exec._dev_key(device))
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         self._exec.check(input)
@@ -1199,7 +1232,7 @@ class FFCResNetGenerator(_HipModule):
             n = 4 if tiles >= 256 else 1                    # 12-wave workgroup per tile and CU), so nothing splits below 256 tiles; four parts
             while n > 1 and B % n:                          # measured >= two at every size tried (profiles/r05_split_batch.txt)
                 n //= 2
-            if n > 1 and self._split_ok.get((tuple(int(v) for v in shape), str(torch.device(device)))) is False:
+            if n > 1 and self._split_ok.get(self._plan_key(shape, device)) is False:
                 return 1                                    # this runtime does not run the parts side by side (verify_split)
             return n
         n = int(n)
@@ -1242,7 +1275,7 @@ class FFCResNetGenerator(_HipModule):
         return plan['out_full']
 
     def _plan_for(self, shape, device) -> dict:
-        key = (tuple(shape), str(device))
+        key = self._plan_key(shape, device)
         n = self._split_parts(shape, device)
         plan = self._plans.get(key)
         if plan is not None and plan.get('nsplit', 1) != n:
@@ -1280,26 +1313,29 @@ class FFCResNetGenerator(_HipModule):
 
     def tune_split(self, shape, device) -> int:
         """``verify_split``: decide ONCE per input shape whether the split plan the rule proposes really runs its parts side by side (see
-        __init__).  Builds and captures both graphs on uniform-random input, replays them alternately (best of four each), keeps the winner in the plan cache and
-        returns its part count.  Host-synchronising; never called inside a stream capture."""
+        __init__).  Builds and captures both graphs on uniform-random input (under a scratch range flag: what noise raises is nobody's
+        report), replays them alternately -- 9 timed replays each after a warm-up pair -- and keeps the split plan only when its MEDIAN is at
+        least ``split_margin`` (2 %) below the one-part plan's: a tie is the one-part plan, so two processes on one box decide alike.  The
+        loser's buffers and graph are released before this returns; the decision is recorded in ``split_decisions`` (and ``split_timing``).
+        Host-synchronising; never called inside a stream capture."""
         device = torch.device(device)
-        key = (tuple(int(v) for v in shape), str(device))
+        key = self._plan_key(shape, device)
         n = self._split_parts(shape, device)
         if (n <= 1 or self.split_batch is not None or not self.verify_split or key in self._split_ok or device.type != 'cuda'
                 or torch.cuda.is_current_stream_capturing()):
             return n
         x = torch.rand(tuple(shape), device=device, dtype=torch.float32)
-        cand = {}
-        with self._exec.range_scope(x, self.precision, deferred=True):
+        cand, times = {}, {n: [], 1: []}
+        with self._exec.scratch_range_scope(x, self.precision):
             for parts in (n, 1):
                 plan = self._build_split_plan(shape, device, parts) if parts > 1 else self._build_plan(shape, device)
                 plan['static_in'] = x
                 self._capture(plan, device)
-                cand[parts] = [float('inf'), plan]
-            # alternate the two graphs (the first replays after an idle period run on ramping clocks) and keep each one's best replay
-            for rnd in range(5):
+                cand[parts] = plan
+            # alternate the two graphs (the first replays after an idle period run on ramping clocks)
+            for rnd in range(1 + self.split_replays):
                 for parts in (n, 1):
-                    g = cand[parts][1]['graph']
+                    g = cand[parts]['graph']
                     if rnd == 0:
                         g.replay()                            # warm-up, untimed
                         continue
@@ -1308,14 +1344,20 @@ class FFCResNetGenerator(_HipModule):
                     g.replay()
                     t1.record()
                     torch.cuda.synchronize(device)
-                    cand[parts][0] = min(cand[parts][0], t0.elapsed_time(t1))
-        ok = cand[n][0] <= cand[1][0]
+                    times[parts].append(t0.elapsed_time(t1))
+        med = {parts: sorted(ts)[len(ts) // 2] for parts, ts in times.items()}
+        ok = med[n] <= (1.0 - self.split_margin) * med[1]
         self._split_ok[key] = ok
-        self.split_timing = {key: dict(parts=n, ms_split=round(cand[n][0], 3), ms_one_part=round(cand[1][0], 3), kept=n if ok else 1)}
-        plan = cand[n if ok else 1][1]            # (its captured graph and its input buffer -- the random tensor -- stay: forward stages into it,
+        self.split_decisions[key] = dict(parts=n, ms_split=round(med[n], 3), ms_one_part=round(med[1], 3), kept=n if ok else 1,
+                                         margin=self.split_margin, replays=self.split_replays)
+        self.split_timing = {key: self.split_decisions[key]}
+        plan = cand.pop(n if ok else 1)           # (its captured graph and its input buffer -- the random tensor -- stay: forward stages into it,
+        cand.clear()                              #  input_buffer hands it to a caller that writes its input in place); the loser is released now
+        del x
         while len(self._plans) >= max(1, self.max_plans):
             self._plans.popitem(last=False)
-        self._plans[key] = plan                   #  input_buffer hands it to a caller that writes its input in place)
+        self._plans[key] = plan
+        torch.cuda.empty_cache()
         return n if ok else 1
 
     def _forward(self, x: torch.Tensor) -> torch.Tensor:

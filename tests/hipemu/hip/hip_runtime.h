@@ -325,6 +325,7 @@ static inline void hipemu_buf_store_b64(lama_buf_t r, hipemu_u32x2 v, unsigned v
 }
 #define LAMA_BUF_LOAD_B64(rsrc, voff, soff) hipemu_buf_load_b64(rsrc, voff, soff)
 #define LAMA_PIN_AGPR(x) ((void)0)
+#define LAMA_LDS_AS
 #define LAMA_BUF_STORE_B64(rsrc, val, voff, soff) hipemu_buf_store_b64(rsrc, val, voff, soff)
 #define LAMA_BUF_STORE_B32(rsrc, val, voff, soff) hipemu_buf_store_b32(rsrc, val, voff, soff)
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
