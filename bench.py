@@ -31,7 +31,7 @@ The JSON line also carries
                    (MIOpen convs, rocFFT rfftn / irfftn) on the same GPU, timed in a subprocess outside the
                    timed region (the oracle's functional restatement moved to cuda; /root/reference does not
                    exist on the GPU box).
-  value_host_fed -- SURVEY.md 8(d)'s "includes H2D/D2H" rate: the same steps fed from pinned host buffers (fp32 image + mask in, u8 out) over
+  value_host_fed -- SURVEY.md 8(d)'s "includes H2D/D2H" rate: the same steps fed from pinned host buffers (round 6: u8 HWC image + u8 mask in as they are on disk, u8 out) over
                    PCIe the way lama_amd.predict serves a directory (HostFedStep: upload of batch k+1, compute of batch k and download of
                    batch k-1 as parallel branches of one captured hipGraph per step); beside it the serial form (copies on the compute
                    stream) and round 4's copy-stream pipeline around plain launches.  `value` stays the resident-input rate the bench
@@ -260,7 +260,7 @@ def cpu_one_thread_leg():
     print(json.dumps(dict(images_per_s=round(1.0 / dt, 4), images=1, threads=torch.get_num_threads(), seconds=round(dt, 1))), flush=True)
 
 
-def configs4_refine_leg(model, device, res=2048, n_iters=15):
+def configs4_refine_leg(model, device, res=2048, n_iters=15, px_budget=4194304):
     """BASELINE configs[4]: refine_predict on one synthetic res x res image (refiner defaults of configs/prediction/default.yaml with
     px_budget = 4194304 so that the full resolution is kept): seconds per image, second run (plans and packed reverse-pass weights
     cached)."""
@@ -276,15 +276,145 @@ def configs4_refine_leg(model, device, res=2048, n_iters=15):
         batch = dict(image=img, mask=mask, unpad_to_size=[torch.tensor([res]), torch.tensor([res])])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        R.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=n_iters, lr=0.002, min_side=512, max_scales=3, px_budget=4194304)
+        R.refine_predict(batch, model, gpu_ids='0,', modulo=8, n_iters=n_iters, lr=0.002, min_side=512, max_scales=3, px_budget=px_budget)
         torch.cuda.synchronize()
         dts.append(time.perf_counter() - t0)
     for plan_owner in (model.generator,):
         plan_owner._plans.clear()
     torch.cuda.empty_cache()
     return dict(value=round(dts[-1], 3), unit='s per image', first_run_s=round(dts[0], 3),
-                workload=f'big-lama refine_predict, 1 x {res}x{res}, n_iters={n_iters}, 3 scales (512 / 1024 / 2048), forward f16x3 + reverse pass bf16x3',
+                workload=f'big-lama refine_predict, 1 x {res}x{res}, n_iters={n_iters}, px_budget={px_budget}' + (', 3 scales (512 / 1024 / 2048)' if px_budget >= res * res else ' (configs/prediction/default.yaml:24: the image is first rescaled to ~1341^2 -> padded 1344^2, bottleneck planes 168 x 168 = 2^3 3 7, then the pyramid of refinement.py:203-211)') + ', forward f16x3 + reverse pass bf16x3',
                 peak_memory_gib=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+
+
+def photo_leg(model, device, lib, steps=8):
+    """VERDICT r5 Next #1: the plane sizes real inputs produce.  Step time of the hot path (u8 in, generator, u8 out; hipGraph replay) at photo-sized
+    inputs -- bottleneck planes 135 x 240, 90 x 160, 125 x 188 (= 5^3 x 2^2 47: a large prime factor) -- and at their power-of-two neighbour
+    1024 x 2048 on the SAME box; ns per pixel and the ratio to the neighbour's.  Accuracy: the first image of each shape on the parity tests'
+    seeded BN-calibrated weights against the CPU fp32 oracle (the checker, outside every timed loop)."""
+    shapes = [(1, 1024, 2048), (1, 1080, 1920), (4, 720, 1280), (1, 1000, 1504)]
+    out, ref_ns = {}, None
+    gen = model.generator
+    gen.use_graph = True
+    for (b, h, w) in shapes:
+        g = torch.Generator().manual_seed(h + w)
+        img_u8 = torch.randint(0, 256, (b, h, w, 3), generator=g, dtype=torch.uint8).to(device)
+        mask_u8 = torch.zeros(b, h, w, dtype=torch.uint8)
+        mask_u8[:, h // 4: h // 4 + h // 2, w // 4: w // 4 + w // 2] = 255
+        mask_u8 = mask_u8.to(device)
+        u8 = torch.empty(b, h, w, 3, dtype=torch.uint8, device=device)
+        for _ in range(3):
+            model.forward_u8(img_u8, mask_u8, None, u8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.forward_u8(img_u8, mask_u8, None, u8)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ns = dt * 1e9 / (b * h * w)
+        if ref_ns is None:
+            ref_ns = ns
+        out[f'{b}x{h}x{w}'] = dict(ms_per_step=round(dt * 1e3, 3), images_per_s=round(b / dt, 2), ns_per_pixel=round(ns, 3),
+                                   vs_1024x2048_per_pixel=round(ns / ref_ns, 3), bottleneck_plane=f'{h // 8}x{w // 8}')
+        gen._plans.clear()
+        torch.cuda.empty_cache()
+    try:        # accuracy on calibrated weights (one image per photo shape)
+        O, _, cfg = _cpu_state(model)
+        torch.set_num_threads(max(1, min(CPU_THREADS_CAP, os.cpu_count() or 1)))
+        keep = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        sd = {'generator.' + k: v for k, v in O.make_synthetic_state_dict(cfg, seed=0, calib_hw=64).items()}
+        model.load_state_dict(sd, strict=True)
+        for (b, h, w) in shapes[1:]:
+            b1 = O.make_synthetic_batch(1, h, w, seed=h)
+            with torch.no_grad():
+                ref = O.training_module_forward(dict(image=b1['image'].clone(), mask=b1['mask'].clone()), sd, cfg)['inpainted']
+            got = model(dict(image=b1['image'].to(device), mask=b1['mask'].to(device)))['inpainted'].cpu()
+            out[f'{b}x{h}x{w}']['max_abs_vs_oracle'] = float(f'{float((got - ref).abs().max()):.3e}')
+            gen._plans.clear()
+        model.load_state_dict(keep, strict=True)
+    except Exception as e:      # noqa: BLE001
+        out['accuracy_error'] = repr(e)[:300]
+    out['note'] = ('round 6: mixed-radix plane-in-LDS rfft2 / irfft2 for any plane (fft_mr_dev.inc), 128-pixel conv tiles shaped by rounds; the local conv of '
+                   'these planes is the direct kernel (the Winograd launch takes W in {32, 64, 128, 256} only).  1 x 1000 x 1504 is 184 tiles of 128 pixels on 256 CUs: '
+                   'every launch runs on three quarters of the chip -- its per-pixel ratio is utilisation, not a slow path')
+    torch.cuda.empty_cache()
+    return out
+
+
+def predict_cli_leg(model, n_images=512, res=512, io_threads=(8, 16, 32, 64)):
+    """VERDICT r5 Next #3: what 8 GPUs will really run -- `python -m lama_amd.predict` end to end on a directory (bin/predict.py:66-94): PNG decode,
+    u8 upload, the step, u8 download, PNG encode + write, with plan build / graph capture of the bucket inside the wall time.  512 synthetic
+    512 x 512 PNG pairs on tmpfs, a checkpoint directory written from this model; one subprocess per io_threads value.  Also: host CPU-seconds per
+    image of the PNG decode (image + mask) and of the encode, single thread, in this process."""
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    import yaml
+    from PIL import Image
+    root = tempfile.mkdtemp(prefix='lama_cli_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    out = {}
+    try:
+        mdir, indir = os.path.join(root, 'model'), os.path.join(root, 'in')
+        os.makedirs(os.path.join(mdir, 'models'))
+        os.makedirs(indir)
+        with open(os.path.join(mdir, 'config.yaml'), 'w') as f:
+            yaml.safe_dump(dict(training_model=dict(kind='default', concat_mask=True), generator=dict(BIG_LAMA)), f)
+        torch.save({'state_dict': {k: v.detach().cpu() for k, v in model.state_dict().items()}}, os.path.join(mdir, 'models', 'best.ckpt'))
+        rng = np.random.RandomState(7)
+        base = rng.randint(0, 256, (res + 64, res + 64, 3)).astype('uint8')       # SURVEY 8(d): uniform noise (the worst case for PNG: incompressible)
+
+        def make(i):
+            oy, ox = (i * 7) % 64, (i * 13) % 64
+            Image.fromarray(base[oy:oy + res, ox:ox + res]).save(os.path.join(indir, f'im{i:04d}.png'), compress_level=1)
+            m = np.zeros((res, res), 'uint8')
+            m[res // 4: res // 4 + res // 2, res // 4: res // 4 + res // 2] = 255
+            Image.fromarray(m).save(os.path.join(indir, f'im{i:04d}_mask001.png'))
+
+        with ThreadPoolExecutor(min(32, os.cpu_count() or 8)) as ex:
+            list(ex.map(make, range(n_images)))
+        # host cost of the IO per image (single thread)
+        t0 = time.process_time()
+        for i in range(32):
+            np.asarray(Image.open(os.path.join(indir, f'im{i:04d}.png')).convert('RGB'))
+            np.asarray(Image.open(os.path.join(indir, f'im{i:04d}_mask001.png')).convert('L'))
+        dec = (time.process_time() - t0) / 32
+        arr = np.asarray(Image.open(os.path.join(indir, 'im0000.png')).convert('RGB'))
+        t0 = time.process_time()
+        for i in range(32):
+            Image.fromarray(arr).save(os.path.join(root, 'enc.png'), compress_level=1)
+        enc = (time.process_time() - t0) / 32
+        out['host_cpu_s_per_image'] = dict(png_decode_image_and_mask=round(dec, 5), png_encode_result=round(enc, 5), note='single thread, PIL; zlib level 1 on write = cv2.imwrite\'s PNG default (what bin/predict.py:94 uses); uniform-noise images: incompressible, the expensive end of real content')
+        runs = {}
+        for T in io_threads:
+            od = os.path.join(root, f'out{T}')
+            t0 = time.perf_counter()
+            r = subprocess.run([sys.executable, '-m', 'lama_amd.predict', f'model.path={mdir}', f'indir={indir}', f'outdir={od}', f'io_threads={T}'],
+                               cwd=ROOT, capture_output=True, text=True, timeout=600)
+            wall = time.perf_counter() - t0
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('wrote ')]
+            if r.returncode != 0 or not line:
+                runs[str(T)] = dict(error=(r.stderr or r.stdout)[-300:])
+                continue
+            secs = float(line[-1].split(' in ')[1].split(' s')[0])
+            runs[str(T)] = dict(images_per_s=round(n_images / secs, 1), loop_s=round(secs, 3), process_wall_s=round(wall, 1))
+            shutil.rmtree(od, ignore_errors=True)
+        out['by_io_threads'] = runs
+        ok = {int(k): v['images_per_s'] for k, v in runs.items() if 'images_per_s' in v}
+        if ok:
+            best = max(ok.values())
+            sat = min(k for k, v in ok.items() if v >= 0.97 * best)
+            out['value'], out['unit'], out['saturates_at_io_threads'] = best, 'images/s', sat
+            cores = 830.0 * (dec + enc)
+            out['host_cores_for_8_ranks_at_830_images_per_s'] = round(8 * cores, 1)
+            out['statement'] = (f'one rank at 830 images/s needs {cores:.1f} host cores of PNG decode + encode ({dec * 1e3:.1f} + {enc * 1e3:.1f} ms per image on this host); '
+                                f'eight ranks need {8 * cores:.0f} -- of the {os.cpu_count()} logical cores of this box')
+        out['workload'] = (f'python -m lama_amd.predict on {n_images} synthetic {res}x{res} PNG pairs on tmpfs (bin/predict.py:66-94 end to end; loop_s includes the plan build + '
+                           'graph capture of the one shape bucket, excludes process start and checkpoint load)')
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    return out
 
 
 def sustained_mfma_peak(device, seconds=0.25):
@@ -433,6 +563,12 @@ class StepLoop:
         self.step_no = 0
         self.gathers = 0
         model.keep_predicted_image = False          # 'inpainted' is all this loop reads (as predict.py): no copy of the generator's output
+        # round 6: the step runs the way lama_amd.predict runs it -- u8 HWC image + u8 mask resident in HBM (what is on disk), / 255 and the blend's u8
+        # quantisation inside the two elementwise launches around the generator (forward_u8, ABI v110).  The synthetic image IS k / 255 and the mask
+        # {0, 1}, so the u8 operands are exact and the result equals the fp32-tensor step's bit for bit (checked once in main()).
+        self.img_u8 = (img * 255.0).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+        self.mask_u8 = (mask[:, 0] * 255.0).round().to(torch.uint8).contiguous()
+        self.use_u8 = hasattr(model, 'forward_u8') and os.environ.get('LAMA_BENCH_U8', '1') != '0'
 
     def step(self, collect=True):
         use_dist = self.dist is not None and collect
@@ -441,9 +577,12 @@ class StepLoop:
         if use_dist and self.gather_work[k] is not None:
             self.gather_work[k].wait()          # device-side on a GPU: the compute stream waits for gather k - 2 (long done) before reusing its buffers
             self.gather_work[k] = None
-        out = self.model(dict(image=self.img, mask=self.mask))
         main = torch.cuda.current_stream(self.device) if self.on_gpu else None
-        self.lib.quantize_u8_hwc(L.view(out['inpainted']), self.u8_ring[k], B, H, W, main.cuda_stream if self.on_gpu else 0)
+        if self.use_u8:
+            self.model.forward_u8(self.img_u8, self.mask_u8, None, self.u8_ring[k], binarize=False)
+        else:
+            out = self.model(dict(image=self.img, mask=self.mask))
+            self.lib.quantize_u8_hwc(L.view(out['inpainted']), self.u8_ring[k], B, H, W, main.cuda_stream if self.on_gpu else 0)
         if use_dist:
             if self.on_gpu:
                 self.quantized[k].record(main)
@@ -528,6 +667,8 @@ def main():
     ap.add_argument('--split-batch', type=int, default=0, choices=[0, 1, 2, 4], help='parts of the batch as parallel branches of the hipGraph: 0 = the generator\'s rule, verified by timing once per shape (config.split_check); 1 / 2 / 4 force it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the PyTorch-ROCm eager comparator (subprocess)')
+    ap.add_argument('--no-cli-leg', action='store_true', help='skip the end-to-end python -m lama_amd.predict leg (subprocesses)')
+    ap.add_argument('--no-photo-leg', action='store_true', help='skip the photo-sized-input leg')
     ap.add_argument('--lib', default=None, help='A/B runs: another build of liblama_hip.so (e.g. lama_amd/lib/liblama_hip_prof.so, whose kernel '
                                                 'switches read LAMA_* variables); the default is the in-tree product library')
     ap.add_argument('--cpu-one-thread-leg', action='store_true', help=argparse.SUPPRESS)
@@ -593,19 +734,23 @@ def main():
     if not range_ok:
         raise SystemExit('bench.py: an activation left the fp16 split\'s range during the timed steps: the run is void')
 
-    # the same K steps fed from / drained to pinned HOST buffers (SURVEY.md 8(d) "includes H2D/D2H"): fp32 image + mask in, u8 out,
+    # the same K steps fed from / drained to pinned HOST buffers (SURVEY.md 8(d) "includes H2D/D2H"): u8 image + mask in, u8 out,
     # copies on the compute stream (serial, not overlapped).  Reported beside `value`, never as `value`.
-    dt_pcie = dt_piped = dt_piped_graph = dt_replay = hf_mode = None
+    dt_pcie = dt_piped = dt_piped_graph = dt_replay = dt_host = hf_mode = None
     if world == 1:
-        h_img, h_mask = img.cpu().pin_memory(), mask.cpu().pin_memory()
+        h_img, h_mask = loop.img_u8.cpu().pin_memory(), loop.mask_u8.cpu().pin_memory()      # (round 6) what is on disk: u8 HWC image + u8 mask, 8.4 MB per step
         h_u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8).pin_memory()
-        d_img, d_mask = torch.empty_like(img), torch.empty_like(mask)
+        d_img, d_mask = torch.empty_like(loop.img_u8), torch.empty_like(loop.mask_u8)
+        # the u8 step against the fp32-tensor step of round 5 (the reference's host code: / 255, then the module's forward + u8): the same bits
+        ref_u8 = torch.empty_like(u8)
+        lib.quantize_u8_hwc(L.view(model(dict(image=img, mask=mask))['inpainted']), ref_u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
+        u8_step_bit_identical = bool(torch.equal(ref_u8, model.forward_u8(loop.img_u8, loop.mask_u8, None, torch.empty_like(u8), binarize=False)))
+        assert u8_step_bit_identical, 'forward_u8 differs from forward + quantize_u8_hwc'
 
         def step_pcie():
             d_img.copy_(h_img, non_blocking=True)
             d_mask.copy_(h_mask, non_blocking=True)
-            out = model(dict(image=d_img, mask=d_mask))
-            lib.quantize_u8_hwc(L.view(out['inpainted']), u8, BATCH, RES, RES, torch.cuda.current_stream().cuda_stream)
+            model.forward_u8(d_img, d_mask, None, u8, binarize=False)
             h_u8.copy_(u8, non_blocking=True)
 
         step_pcie()
@@ -626,6 +771,7 @@ def main():
             for q in range(2):
                 hs.h_img[q].copy_(h_img)
                 hs.h_mask[q].copy_(h_mask)
+                hs.h_sizes[q][:] = torch.tensor([RES, RES], dtype=torch.int32)
 
             def run(nsteps):
                 hs.prime(0)
@@ -645,6 +791,7 @@ def main():
         hf_mode = HostFedStep(model, BATCH, RES, RES, device).mode          # what `auto` (predict.py's default) picks for this shape
         dt_piped = host_fed('streams')
         dt_piped_graph = host_fed('graph')
+        dt_host = host_fed('host')
         model.generator._plans.clear()
 
     # instrumented eager steps: per-kernel durations with HIP events on the launch stream
@@ -854,6 +1001,27 @@ def main():
         model.generator.set_precision(precision)
         model.generator.use_graph = not args.no_graph
 
+    # extra legs (rank 0, N = 1), round 6: the default refinement budget, photo-sized inputs, the CLI end to end.  Never `value`.
+    c5d_leg = ph_leg = cli_leg = None
+    if rank == 0 and world == 1 and not args.no_f32_leg and BATCH == 8 and RES == 512:
+        for name, fn in (('c5d', lambda: configs4_refine_leg(model, device, px_budget=1800000)), ('photo', lambda: photo_leg(model, device, lib)),
+                         ('cli', lambda: predict_cli_leg(model))):
+            if (name == 'cli' and args.no_cli_leg) or (name == 'photo' and args.no_photo_leg):
+                continue
+            try:
+                r_ = fn()
+            except Exception as e:      # noqa: BLE001
+                r_ = dict(error=repr(e)[:300])
+            if name == 'c5d':
+                c5d_leg = r_
+            elif name == 'photo':
+                ph_leg = r_
+            else:
+                cli_leg = r_
+            model.generator.set_precision(precision)
+            model.generator.use_graph = not args.no_graph
+            model.generator._plans.clear()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(model)
@@ -871,6 +1039,7 @@ def main():
     if rank == 0:
         n_seen = ranks_seen(dist if use_dist else None, world, args.gpus)
         total_images = world * BATCH * args.steps
+        dt_hf = None if dt_replay is None else {'graph': dt_piped_graph, 'replay': dt_replay, 'host': dt_host, 'streams': dt_piped}[hf_mode]
         line = {
             'metric': f'inpainted images/sec at {RES}x{RES} big-lama',
             'value': round(total_images / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'n_ranks_seen': n_seen,
@@ -884,13 +1053,16 @@ def main():
                        'split_batch': f'{nsplit} parts of {BATCH // nsplit} images as parallel branches of the one hipGraph (generator.split_batch)' if nsplit > 1 else 1,
                        'split_check': split_check},
             'roofline': roof, 'roofline_ffc': roof_ffc, 'cpu_baseline': cpu, 'exact_f32_leg': f32_leg,
-            'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg, 'batch16_leg': b16_leg,
+            'pytorch_rocm_eager': eager, 'configs2_fp16_leg': c3_leg, 'configs4_refine_leg': c5_leg, 'configs4_refine_default_leg': c5d_leg, 'photo_leg': ph_leg, 'predict_cli_leg': cli_leg, 'batch16_leg': b16_leg,
             'value_host_fed': None if dt_replay is None else dict(
-                value=round(BATCH * args.steps / (dt_piped_graph if hf_mode == 'graph' else dt_replay), 3), unit='images/s',
-                ms_per_step=round((dt_piped_graph if hf_mode == 'graph' else dt_replay) / args.steps * 1e3, 3),
-                vs_resident=round(dt / (dt_piped_graph if hf_mode == 'graph' else dt_replay), 4), mode=hf_mode,
-                note=f'SURVEY.md 8(d) metric (i) "includes H2D/D2H": the same {args.steps} steps fed from pinned host buffers (fp32 image + mask, '
-                     f'{BATCH * 4 * RES * RES * 4 / 1e6:.1f} MB in; u8 images, {BATCH * 3 * RES * RES / 1e6:.1f} MB out per step over PCIe), the way '
+                host_synchronised_copy_streams=dict(value=round(BATCH * args.steps / dt_host, 3), ms_per_step=round(dt_host / args.steps * 1e3, 3),
+                    note='HostFedStep(mode=host), round 6: the compute queued first, then the HOST waits for the previous step and queues the next upload / previous download on the copy streams -- no device-side fork / join between the queues'),
+                u8_step_bit_identical_to_fp32_tensor_step=u8_step_bit_identical,
+                value=round(BATCH * args.steps / dt_hf, 3), unit='images/s',
+                ms_per_step=round(dt_hf / args.steps * 1e3, 3),
+                vs_resident=round(dt / dt_hf, 4), mode=hf_mode,
+                note=f'SURVEY.md 8(d) metric (i) "includes H2D/D2H": the same {args.steps} steps fed from pinned host buffers (round 6: u8 HWC image + u8 mask as on disk, '
+                     f'{BATCH * 4 * RES * RES / 1e6:.1f} MB in -- / 255, padding and mask > 0 run on the device; u8 images, {BATCH * 3 * RES * RES / 1e6:.1f} MB out per step over PCIe), the way '
                      'lama_amd.predict serves a directory: HostFedStep(mode=auto) -- H2D of batch k+1, compute of batch k, D2H of batch k-1 per launch, in '
                      'the form `mode` names (graph: one captured hipGraph per step with the copies as branches beside the parts of the batch; replay: copy '
                      'streams beside the replay of the generator\'s graph); outputs equal the serial leg bit for bit.  `value` itself is the '

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LAMA_HIP_VERSION 109
+#define LAMA_HIP_VERSION 110
 
 #define LAMA_OK 0
 #define LAMA_ERR_BAD_ARG (-1)
@@ -221,6 +221,20 @@ int lama_blend_fwd(void* stream, const lama_tensor* image, const lama_tensor* ma
  * src [B,3,H,W] fp32 -> dst u8 [B, crop_h, crop_w, 3] (RGB). */
 int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, uint8_t* dst, int32_t batch, int32_t crop_h,
                              int32_t crop_w);
+
+/* (v110) The two ends of the predict step on what is on DISK: u8 HWC image [B][Hp][Wp][3] + u8 mask [B][Hp][Wp] (device pointers), each image's
+ * valid h x w region in the top-left corner of its slot, sizes = int32 [B][2] (h, w) on the device (NULL: every image fills its slot; h = 0: an
+ * empty slot of a partial batch -> zeros).  The kernels do what the reference's host code does per image:
+ *   image.astype('float32') / 255 (evaluation/data.py:12-20: the same IEEE fp32 division), symmetric padding bottom / right up to (Hp, Wp)
+ *   (data.py:29-33, np.pad mode='symmetric': row h + i = row h - 1 - i), mask > 0 (bin/predict.py:84; binarize == 0: mask / 255),
+ * so a step uploads 4 bytes per pixel instead of 16 and the host neither converts nor pads.
+ *   lama_mask_compose_u8_fwd:   out [B,4,Hp,Wp] fp32 = cat(img * (1 - mask), mask)                      (trainers/default.py:59,67-68)
+ *   lama_blend_quantize_u8_fwd: dst u8 [B][Hp][Wp][3] = clip((mask * pred + (1 - mask) * img) * 255, 0, 255) truncated   (default.py:71 + bin/predict.py:86-92)
+ * Bit-identical to lama_mask_compose_fwd / lama_blend_fwd + lama_quantize_u8_hwc_fwd on the fp32 tensors the host would have built. */
+int lama_mask_compose_u8_fwd(void* stream, const uint8_t* image_hwc, const uint8_t* mask, const int32_t* sizes, const lama_tensor* out,
+                             int32_t batch, int32_t binarize);
+int lama_blend_quantize_u8_fwd(void* stream, const uint8_t* image_hwc, const uint8_t* mask, const int32_t* sizes, const lama_tensor* pred,
+                               uint8_t* dst_hwc, int32_t batch, int32_t binarize);
 
 /* Stand-alone per-channel affine + activation: y = act(x*scale[c] + shift[c]) (scale/shift NULL = identity).
  * Used when a caller runs generator.model layer by layer and hits a bare nn.BatchNorm2d (eval) /

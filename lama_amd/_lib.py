@@ -19,7 +19,7 @@ CONV_COOPERATIVE = 1
 CONV_DEFER_OUT = 2          # lama_winograd_conv3x3_fwd: the GEMM launch only (include/lama_hip.h)
 CONV_SIBLINGS_SHIFT = 8     # (v109) bits 8..10: log2 of the number of sibling launches that share the chip with this one
 DT_F32, DT_F16 = 0, 1
-ABI_VERSION = 109      # LAMA_HIP_VERSION of include/lama_hip.h
+ABI_VERSION = 110      # LAMA_HIP_VERSION of include/lama_hip.h
 PREC_NAMES = {'f32': PREC_F32, 'bf16x3': PREC_BF16X3, 'f16x3': PREC_F16X3, 'f16': PREC_F16}
 
 _DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'liblama_hip.so')
@@ -120,6 +120,10 @@ class LamaLib:
         L.lama_blend_fwd.argtypes = [vp, T, T, T, T, i32]
         L.lama_quantize_u8_hwc_fwd.restype = C.c_int
         L.lama_quantize_u8_hwc_fwd.argtypes = [vp, T, vp, i32, i32, i32]
+        L.lama_mask_compose_u8_fwd.restype = C.c_int
+        L.lama_mask_compose_u8_fwd.argtypes = [vp, vp, vp, vp, T, i32, i32]
+        L.lama_blend_quantize_u8_fwd.restype = C.c_int
+        L.lama_blend_quantize_u8_fwd.argtypes = [vp, vp, vp, vp, T, vp, i32, i32]
         L.lama_affine_act_fwd.restype = C.c_int
         L.lama_affine_act_fwd.argtypes = [vp, T, vp, vp, i32, T, i32]
         L.lama_reflect_pad_fwd.restype = C.c_int
@@ -345,6 +349,17 @@ class LamaLib:
 
     def blend(self, image: Tensor4, mask: Tensor4, pred: Tensor4, out: Tensor4, batch: int, stream: int = 0):
         self.check(self._l.lama_blend_fwd(stream, C.byref(image), C.byref(mask), C.byref(pred), C.byref(out), batch), 'lama_blend_fwd')
+
+    def mask_compose_u8(self, image_hwc: torch.Tensor, mask: torch.Tensor, sizes, out: Tensor4, batch: int, binarize: bool = True, stream: int = 0):
+        """(v110) u8 HWC image [B,Hp,Wp,3] + u8 mask [B,Hp,Wp] (+ int32 sizes [B,2] or None) -> the generator's input [B,4,Hp,Wp] fp32."""
+        self.check(self._l.lama_mask_compose_u8_fwd(stream, image_hwc.data_ptr(), mask.data_ptr(), None if sizes is None else sizes.data_ptr(),
+                                                    C.byref(out), batch, int(bool(binarize))), 'lama_mask_compose_u8_fwd')
+
+    def blend_quantize_u8(self, image_hwc: torch.Tensor, mask: torch.Tensor, sizes, pred: Tensor4, dst: torch.Tensor, batch: int,
+                          binarize: bool = True, stream: int = 0):
+        """(v110) blend (default.py:71) + u8 HWC quantisation (bin/predict.py:86-92) of the generator's output against the u8 operands."""
+        self.check(self._l.lama_blend_quantize_u8_fwd(stream, image_hwc.data_ptr(), mask.data_ptr(), None if sizes is None else sizes.data_ptr(),
+                                                      C.byref(pred), dst.data_ptr(), batch, int(bool(binarize))), 'lama_blend_quantize_u8_fwd')
 
     def quantize_u8_hwc(self, src: Tensor4, dst: torch.Tensor, batch: int, crop_h: int, crop_w: int, stream: int = 0):
         self.check(self._l.lama_quantize_u8_hwc_fwd(stream, C.byref(src), dst.data_ptr(), batch, crop_h, crop_w), 'lama_quantize_u8_hwc_fwd')

@@ -70,6 +70,78 @@ __global__ __launch_bounds__(LAMA_NTHREADS) void quantize_u8_hwc_kernel(QuantPar
     }
 }
 
+// ---- round 6 (v110): the predict step fed with what is on disk -- u8 HWC image + u8 mask, unpadded -- instead of fp32 NCHW tensors the host
+// converted and padded (33.6 MB instead of 8.4 MB over PCIe per 8 x 512^2 step, and a float conversion + np.pad per image on the host).
+//   image / 255 in fp32 (evaluation/data.py:12-20: astype('float32') / 255 -- the same IEEE division), symmetric padding at the bottom / right
+//   up to (Hp, Wp) (data.py:29-33: padded row h + i = row h - 1 - i), mask > 0 (bin/predict.py:84) or mask / 255.
+struct U8Params {
+    const uint8_t* img;      // [B][Hp][Wp][3], the valid part in the top-left h x w corner of each image's slot
+    const uint8_t* mask;     // [B][Hp][Wp]
+    const int32_t* sizes;    // [B][2] = (h, w) of each image, or null: every image is Hp x Wp
+    const float* pred;       // blend: [B,3,Hp,Wp]
+    long long pred_bs;
+    float* out;              // compose: [B,4,Hp,Wp] fp32
+    long long out_bs;
+    uint8_t* out_u8;         // blend + quantise: [B][Hp][Wp][3]
+    int B, Hp, Wp, binarize;
+};
+__device__ __forceinline__ bool u8_src(const U8Params& p, int b, int y, int x, long long& pix) {
+    int h = p.Hp, w = p.Wp;
+    if (p.sizes) { h = p.sizes[2 * b]; w = p.sizes[2 * b + 1]; }
+    if (h <= 0 || w <= 0) return false;                  // an empty slot of a partial batch: zeros
+    const int ys = y < h ? y : 2 * h - 1 - y, xs = x < w ? x : 2 * w - 1 - x;
+    pix = ((long long)b * p.Hp + (ys < 0 ? 0 : ys)) * p.Wp + (xs < 0 ? 0 : xs);
+    return true;
+}
+// masked_img = cat(img * (1 - mask), mask)  (trainers/default.py:59,67-68) from the u8 operands
+__global__ __launch_bounds__(LAMA_NTHREADS) void mask_compose_u8_kernel(U8Params p) {
+    const long long hw = (long long)p.Hp * p.Wp, total = (long long)p.B * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / hw);
+        const long long px = i - (long long)b * hw;
+        const int y = (int)(px / p.Wp), x = (int)(px - (long long)y * p.Wp);
+        long long sp;
+        float r = 0.f, g = 0.f, bl = 0.f, m = 0.f;
+        if (u8_src(p, b, y, x, sp)) {
+            const uint8_t* im = p.img + sp * 3;
+            r = (float)im[0] / 255.0f; g = (float)im[1] / 255.0f; bl = (float)im[2] / 255.0f;
+            const uint8_t mu = p.mask[sp];
+            m = p.binarize ? (mu > 0 ? 1.0f : 0.0f) : (float)mu / 255.0f;
+        }
+        float* o = p.out + b * p.out_bs + px;
+        const float k = 1.0f - m;
+        o[0] = r * k;
+        o[hw] = g * k;
+        o[2 * hw] = bl * k;
+        o[3 * hw] = m;
+    }
+}
+// inpainted = mask * pred + (1 - mask) * img (default.py:71), then np.clip(x * 255, 0, 255).astype('uint8') in HWC order (bin/predict.py:86-92)
+__global__ __launch_bounds__(LAMA_NTHREADS) void blend_quantize_u8_kernel(U8Params p) {
+    const long long hw = (long long)p.Hp * p.Wp, total = (long long)p.B * hw;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / hw);
+        const long long px = i - (long long)b * hw;
+        const int y = (int)(px / p.Wp), x = (int)(px - (long long)y * p.Wp);
+        long long sp;
+        float im[3] = {0.f, 0.f, 0.f}, m = 0.f;
+        if (u8_src(p, b, y, x, sp)) {
+            const uint8_t* s = p.img + sp * 3;
+            im[0] = (float)s[0] / 255.0f; im[1] = (float)s[1] / 255.0f; im[2] = (float)s[2] / 255.0f;
+            const uint8_t mu = p.mask[sp];
+            m = p.binarize ? (mu > 0 ? 1.0f : 0.0f) : (float)mu / 255.0f;
+        }
+        const float k = 1.0f - m;
+        uint8_t* d = p.out_u8 + i * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (m * p.pred[b * p.pred_bs + c * hw + px] + k * im[c]) * 255.0f;
+            v = fminf(fmaxf(v, 0.0f), 255.0f);
+            d[c] = (uint8_t)v;
+        }
+    }
+}
+
 struct AffineParams {
     const float* x;
     long long x_bs;
@@ -200,6 +272,36 @@ extern "C" int lama_quantize_u8_hwc_fwd(void* stream, const lama_tensor* src, ui
     p.B = batch; p.H = src->H; p.W = src->W; p.ch = crop_h; p.cw = crop_w;
     hipLaunchKernelGGL(quantize_u8_hwc_kernel, dim3(ew_grid((long long)batch * crop_h * crop_w * 3)), dim3(LAMA_NTHREADS), 0,
                        (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+// (v110) the two ends of the predict step on u8 operands: see mask_compose_u8_kernel / blend_quantize_u8_kernel
+extern "C" int lama_mask_compose_u8_fwd(void* stream, const uint8_t* image_hwc, const uint8_t* mask, const int32_t* sizes, const lama_tensor* out,
+                                        int32_t batch, int32_t binarize) {
+    if (!image_hwc || !mask || !out || !out->ptr || batch <= 0 || out->C != 4 || out->H <= 0 || out->W <= 0) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({out})) return LAMA_ERR_UNSUPPORTED;
+    U8Params p;
+    memset(&p, 0, sizeof(p));
+    p.img = image_hwc; p.mask = mask; p.sizes = sizes;
+    p.out = (float*)out->ptr; p.out_bs = out->batch_stride;
+    p.B = batch; p.Hp = out->H; p.Wp = out->W; p.binarize = binarize;
+    hipLaunchKernelGGL(mask_compose_u8_kernel, dim3(ew_grid((long long)batch * out->H * out->W)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
+    LAMA_CHECK_LAUNCH();
+    return LAMA_OK;
+}
+
+extern "C" int lama_blend_quantize_u8_fwd(void* stream, const uint8_t* image_hwc, const uint8_t* mask, const int32_t* sizes, const lama_tensor* pred,
+                                          uint8_t* dst_hwc, int32_t batch, int32_t binarize) {
+    if (!image_hwc || !mask || !pred || !pred->ptr || !dst_hwc || batch <= 0 || pred->C != 3 || pred->H <= 0 || pred->W <= 0) return LAMA_ERR_BAD_ARG;
+    if (!all_f32({pred})) return LAMA_ERR_UNSUPPORTED;
+    U8Params p;
+    memset(&p, 0, sizeof(p));
+    p.img = image_hwc; p.mask = mask; p.sizes = sizes;
+    p.pred = (const float*)pred->ptr; p.pred_bs = pred->batch_stride;
+    p.out_u8 = dst_hwc;
+    p.B = batch; p.Hp = pred->H; p.Wp = pred->W; p.binarize = binarize;
+    hipLaunchKernelGGL(blend_quantize_u8_kernel, dim3(ew_grid((long long)batch * pred->H * pred->W)), dim3(LAMA_NTHREADS), 0, (hipStream_t)stream, p);
     LAMA_CHECK_LAUNCH();
     return LAMA_OK;
 }

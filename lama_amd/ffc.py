@@ -954,6 +954,7 @@ class FFCResNetGenerator(_HipModule):
         self.fuse_conv1 = None            # None = by launch order (below), True / False = forced
         # with the Winograd local conv (FFC.launch) a plan runs on ONE stream with conv1 fused into the global launch (see _build_plan)
         self.serial_with_winograd = True
+        self.serial_when_full = True      # round 6: ... and for direct-conv plans whose bottleneck launches fill the chip (see _build_plan)
         self.fuse_conv1_serial = True
         # the local convs of the residual blocks as a chain of their own on the second stream (SidePipe) instead of a fork + join per
         # layer.  Off: inside a hipGraph ROCm 7.2 spreads that topology over three queues and every edge becomes a ~10 us cross-queue
@@ -1116,7 +1117,14 @@ class FFCResNetGenerator(_HipModule):
         if scratch and scratch.get('wino') is not None and not wino:
             scratch['wino'] = None                   # 33 MB at 8 x 64 x 64 that no launch would read
         serial = wino and self.serial_with_winograd
-        if serial and self.defer_wino_out:
+        if not wino and not serial and self.serial_when_full and res_layers and scratch and scratch.get('x1') is not None:
+            # round 6 (planes the Winograd launch does not take -- any width that is not 32 / 64 / 128 / 256): when the bottleneck launches fill the
+            # chip by themselves (>= 200 tiles of 128 pixels) a second stream has nothing to run the spectral branch ON -- the mixed-radix FFT
+            # workgroups hold a CU's whole LDS -- and one stream with conv1 in the global launch's epilogue wins (1080 x 1920: 13.7 -> 13.1 ms,
+            # 1344^2: 12.8 -> 12.1; 1000 x 1504, 184 tiles: 11.9 -> 12.3, so it keeps its two streams; profiles/r06_odd_shapes.txt)
+            B_, _, H_, W_ = scratch['x1'].shape
+            serial = B_ * ((H_ * W_ + 127) // 128) >= 200
+        if wino and serial and self.defer_wino_out:
             # the Winograd output transform of layer l rides in the rfft2 launch of layer l + 1 (FFC.launch): the partial sums P live until then,
             # i.e. while that rfft2 writes the FIRST spectrum -- P goes behind it, over the second spectrum (written by the spectral GEMM, after
             # that launch) and a tail: 211 + 7.5 MB touched per layer at 8 x 512^2
@@ -1126,7 +1134,7 @@ class FFCResNetGenerator(_HipModule):
             ws = torch.empty(max(scratch['ws'].numel(), spec_elems + wn.numel()), device=device, dtype=torch.float32)
             scratch['ws'], scratch['wino'] = ws, ws[spec_elems:spec_elems + wn.numel()]
             scratch['defer_out'] = True
-        elif serial and self.alias_wino:
+        elif wino and serial and self.alias_wino:
             # one-stream order: the FourierUnit's spectra (rfft2 -> GEMM -> irfft2) are dead when the Winograd launches start and the
             # Winograd partial sums are dead when the next layer's rfft2 starts: one allocation for both (8 x 512^2: 33.5 of 52 MB shared)
             ws, wn = scratch['ws'], scratch['wino']

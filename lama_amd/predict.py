@@ -3,7 +3,7 @@
 
     python -m lama_amd.predict model.path=<dir> indir=<dir> outdir=<dir> \
         [model.checkpoint=best.ckpt] [dataset.img_suffix=.png] [dataset.pad_out_to_modulo=8] [out_ext=.png] \
-        [batch_size=8] [precision=f16x3|bf16x3|f32]
+        [batch_size=8] [precision=f16x3|bf16x3|f32] [io_threads=8]
     python -m torch.distributed.run --nproc-per-node N -m lama_amd.predict ...        # one process per GPU
 
 Same on-disk contract as the reference: masks are ``**/*mask*.png`` (sorted, recursive), the image of a mask
@@ -33,7 +33,8 @@ from . import config as lcfg
 from . import trainers
 
 DEFAULTS = {'model.checkpoint': 'best.ckpt', 'dataset.img_suffix': '.png', 'dataset.pad_out_to_modulo': 8,
-            'out_ext': '.png', 'out_key': 'inpainted', 'batch_size': 8, 'precision': 'f16x3'}   # configs/prediction/default.yaml
+            'out_ext': '.png', 'out_key': 'inpainted', 'batch_size': 8, 'precision': 'f16x3',
+            'io_threads': 8}   # configs/prediction/default.yaml (+ batch_size / precision / io_threads: this driver's own)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -53,7 +54,7 @@ REFINER_DEFAULTS = {'refiner.gpu_ids': '0,', 'refiner.modulo': 8, 'refiner.n_ite
 STRING_KEYS = {'model.path', 'model.checkpoint', 'indir', 'outdir', 'device', 'dataset.kind', 'dataset.img_suffix', 'out_ext', 'out_key',
                'precision', 'refiner.gpu_ids'}
 BOOL_KEYS = {'refine'}
-INT_KEYS = {'dataset.pad_out_to_modulo', 'batch_size', 'refiner.modulo', 'refiner.n_iters', 'refiner.min_side', 'refiner.max_scales',
+INT_KEYS = {'dataset.pad_out_to_modulo', 'batch_size', 'io_threads', 'refiner.modulo', 'refiner.n_iters', 'refiner.min_side', 'refiner.max_scales',
             'refiner.px_budget'}
 FLOAT_KEYS = {'refiner.lr'}
 
@@ -127,6 +128,17 @@ def pad_img_to_modulo(img: np.ndarray, mod: int) -> np.ndarray:
     return np.pad(img, ((0, 0), (0, ceil_modulo(h, mod) - h), (0, ceil_modulo(w, mod) - w)), mode='symmetric')
 
 
+def load_item_u8(mask_path: str, img_path: str):
+    """The same pair as it is on disk: (u8 image [H,W,3], u8 mask [H,W], (H, W)).  ``load_image``'s / 255, ``pad_img_to_modulo`` and
+    bin/predict.py:84's ``mask > 0`` happen on the device (lama_mask_compose_u8_fwd, ABI v110): the host only decodes."""
+    from PIL import Image
+    image = np.asarray(Image.open(img_path).convert('RGB'))
+    mask = np.asarray(Image.open(mask_path).convert('L'))
+    if tuple(mask.shape) != tuple(image.shape[:2]):
+        raise L.LamaError(f'{mask_path}: mask is {mask.shape[1]}x{mask.shape[0]} but {img_path} is {image.shape[1]}x{image.shape[0]}')
+    return image, mask, tuple(image.shape[:2])
+
+
 def load_item(mask_path: str, img_path: str, pad_mod: int):
     """InpaintingDataset.__getitem__, evaluation/data.py:69-83 -> (image [3,H',W'], mask [1,H',W'], (H, W))."""
     image = load_image(img_path, 'RGB')
@@ -168,6 +180,9 @@ def gather_to_root(dist, gathered: Optional[torch.Tensor], part: torch.Tensor, r
     return dist.gather(part, gather_list=parts, dst=root, async_op=True)
 
 
+TUNE_MIN_ROUNDS = 4      # buckets with fewer rounds skip the split-plan timing check and graph mode (HostFedStep(tune=False))
+
+
 class _RangeRestart(Exception):
     """A forward of this run left the fp16 split's range: the generator is on the bf16 split now, the run starts over."""
 
@@ -175,7 +190,9 @@ class _RangeRestart(Exception):
 def _write_png(path: str, rgb: np.ndarray):
     from PIL import Image
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    Image.fromarray(rgb).save(path)         # the reference converts RGB->BGR only because cv2.imwrite expects BGR
+    # the reference converts RGB->BGR only because cv2.imwrite expects BGR; zlib level 1 is cv2.imwrite's PNG default (IMWRITE_PNG_COMPRESSION = 1), PIL's
+    # own default (6) costs 3-5x the CPU time per image for the same pixels
+    Image.fromarray(rgb).save(path, compress_level=1)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -213,13 +230,19 @@ class HostFedStep:
     (multi-rank: the results go through the gather instead) leaves the D2H branch out.  On a CPU device (the emulator tests) the same body
     runs synchronously, unpinned."""
 
-    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'auto'):
+    def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'auto',
+                 u8_input: bool = True, tune: bool = True):
         self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
         self.drain, self.binarize = drain, binarize
-        if mode not in ('auto', 'replay', 'streams', 'graph'):
-            raise L.LamaError(f'HostFedStep mode {mode!r}: auto, replay, streams or graph')
+        if mode not in ('auto', 'replay', 'streams', 'graph', 'host'):
+            raise L.LamaError(f'HostFedStep mode {mode!r}: auto, replay, streams, graph or host')
+        self.one_part = False
+        if mode == 'auto' and not tune:
+            # a bucket of a few rounds (ADVICE r5): tune_split's two plans, two captures and 20 replays -- and graph mode's own captures -- cost more
+            # than they can return; the one-part plan replayed beside the copy streams needs one warm-up and one capture
+            mode, self.one_part = 'replay', True
         if mode == 'auto':      # by measurement (table above): copy nodes overlap only in a graph that has parallel kernel branches already
             gen = model.generator
             split = 1
@@ -230,24 +253,54 @@ class HostFedStep:
                     split = gen.tune_split((self.n, 4, Hp, Wp), self.device) if self.on_gpu else 1
                 finally:
                     gen._assume_graph = keep_ag
-            mode = 'graph' if (self.on_gpu and split > 1) else 'replay'
+            mode = 'host' if self.on_gpu else 'replay'       # round 6 (u8 copies): the host-synchronised copy streams beside whichever plan won, 0.999 of the resident rate (profiles/r06_host_fed.txt)
         self.mode = mode
         pin = dict(pin_memory=True) if self.on_gpu else {}
-        self.h_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
-        self.h_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
+        # round 6: the step is fed with what is on disk -- u8 HWC image, u8 mask, (h, w) per image: 4 bytes per pixel over PCIe instead of 16, no
+        # float conversion / padding on the host (forward_u8).  ``u8_input=False`` keeps the fp32 NCHW form of round 5 (A/B runs, callers with float data).
+        self.u8_input = bool(u8_input) and hasattr(model, 'forward_u8')
+        if self.u8_input:
+            self.h_img = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, **pin) for _ in range(2)]
+            self.h_mask = [torch.zeros(self.n, Hp, Wp, dtype=torch.uint8, **pin) for _ in range(2)]
+            self.h_sizes = [torch.zeros(self.n, 2, dtype=torch.int32, **pin) for _ in range(2)]
+            self.d_img = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.d_mask = [torch.zeros(self.n, Hp, Wp, dtype=torch.uint8, device=self.device) for _ in range(2)]
+            self.d_sizes = [torch.zeros(self.n, 2, dtype=torch.int32, device=self.device) for _ in range(2)]
+        else:
+            self.h_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
+            self.h_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, **pin) for _ in range(2)]
+            self.d_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self.d_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, device=self.device) for _ in range(2)]
+            self.h_sizes = self.d_sizes = None
         self.h_u8 = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, **pin) for _ in range(2)] if drain else None
-        self.d_img = [torch.zeros(self.n, 3, Hp, Wp, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.d_mask = [torch.zeros(self.n, 1, Hp, Wp, dtype=torch.float32, device=self.device) for _ in range(2)]
         self.u8 = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.graphs = [None, None]
         self.done = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
         self._launched = [False, False]
+        self._h2d_issued = [False, False]
         if self.on_gpu:
+            self.h2d = [torch.cuda.Event() for _ in range(2)]
+            self.d2h = [torch.cuda.Event() for _ in range(2)]
             self.s_in, self.s_out = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
 
     # -- host views -----------------------------------------------------------------------------------------------
     def host(self, p: int):
+        """The pinned host set p as numpy views: (image, mask) -- u8 [n,Hp,Wp,3] / [n,Hp,Wp] (``u8_input``; ``put`` fills them) or fp32 NCHW."""
         return self.h_img[p].numpy(), self.h_mask[p].numpy()
+
+    def put(self, p: int, j: int, image: Optional[np.ndarray], mask: Optional[np.ndarray]):
+        """``u8_input``: image j of host set p = a decoded u8 HWC image [h,w,3] + u8 mask [h,w] (top-left corner of the slot), or None: an empty
+        slot of a partial batch."""
+        sz = self.h_sizes[p].numpy()
+        if image is None:
+            sz[j] = (0, 0)
+            return
+        h, w = image.shape[:2]
+        if h > self.Hp or w > self.Wp:
+            raise L.LamaError(f'image {h}x{w} does not fit the bucket {self.Hp}x{self.Wp}')
+        self.h_img[p].numpy()[j, :h, :w] = image
+        self.h_mask[p].numpy()[j, :h, :w] = mask
+        sz[j] = (h, w)
 
     def result(self, p: int) -> np.ndarray:
         return self.h_u8[p].numpy()
@@ -255,6 +308,10 @@ class HostFedStep:
     # -- pieces ---------------------------------------------------------------------------------------------------
     def _compute(self, p: int):
         lib = self.model.generator._exec.lib
+        if self.u8_input:                                                                          # bin/predict.py:82-92 in two elementwise launches + the generator
+            with torch.no_grad():
+                self.model.forward_u8(self.d_img[p], self.d_mask[p], self.d_sizes[p], self.u8[p], binarize=self.binarize)
+            return
         mask = self.d_mask[p]
         batch = dict(image=self.d_img[p], mask=(mask > 0) * 1 if self.binarize else mask)          # bin/predict.py:84
         keep = self.model.keep_predicted_image
@@ -271,6 +328,8 @@ class HostFedStep:
         q = 1 - p
         if not self.on_gpu:
             self.d_img[q].copy_(self.h_img[q]); self.d_mask[q].copy_(self.h_mask[q])
+            if self.u8_input:
+                self.d_sizes[q].copy_(self.h_sizes[q])
             if self.drain:
                 self.h_u8[q].copy_(self.u8[q])
             self._compute(p)
@@ -280,6 +339,8 @@ class HostFedStep:
         with torch.cuda.stream(self.s_in):
             self.d_img[q].copy_(self.h_img[q], non_blocking=True)
             self.d_mask[q].copy_(self.h_mask[q], non_blocking=True)
+            if self.u8_input:
+                self.d_sizes[q].copy_(self.h_sizes[q], non_blocking=True)
         if self.drain:
             self.s_out.wait_stream(main)
             with torch.cuda.stream(self.s_out):
@@ -315,6 +376,8 @@ class HostFedStep:
         set for the batch after next before any ``wait`` has covered this copy."""
         self.d_img[p].copy_(self.h_img[p], non_blocking=self.on_gpu)
         self.d_mask[p].copy_(self.h_mask[p], non_blocking=self.on_gpu)
+        if self.u8_input:
+            self.d_sizes[p].copy_(self.h_sizes[p], non_blocking=self.on_gpu)
         if self.on_gpu:
             torch.cuda.current_stream(self.device).synchronize()
 
@@ -327,18 +390,59 @@ class HostFedStep:
             finally:
                 gen.defer_range_check = keep
             return
+        if self.mode == 'host':
+            # round 6: NO device-side fork / join between the queues.  The compute of this batch is queued first (behind nothing but the event of
+            # its own upload, issued a step ago and long complete); then the HOST waits for the previous step -- the last reader of device set
+            # 1 - p and the producer of u8[1 - p] -- and only then queues the next upload and the previous download on the copy streams, which
+            # therefore need no barrier against the compute queue.  With 4 bytes per pixel up and 3 down the copies are ~0.3 ms of a 9.7 ms step:
+            # the cross-queue dependencies of the other forms cost more than that (profiles/r06_host_fed.txt).
+            q = 1 - p
+            main = torch.cuda.current_stream(self.device)
+            gen = self.model.generator
+            keep = (gen.use_graph, gen.defer_range_check, getattr(gen, 'split_batch', None))
+            gen.use_graph, gen.defer_range_check = True, True
+            if self.one_part:
+                gen.split_batch = 1
+            try:
+                if self._h2d_issued[p]:
+                    main.wait_event(self.h2d[p])
+                self._compute(p)
+            finally:
+                gen.use_graph, gen.defer_range_check = keep[:2]
+                if self.one_part:
+                    gen.split_batch = keep[2]
+            self.done[p].record(main)
+            if self._launched[q]:
+                self.done[q].synchronize()               # host: step k - 1 is complete (step k is queued behind it: the GPU does not idle)
+            with torch.cuda.stream(self.s_in):
+                self.d_img[q].copy_(self.h_img[q], non_blocking=True)
+                self.d_mask[q].copy_(self.h_mask[q], non_blocking=True)
+                if self.u8_input:
+                    self.d_sizes[q].copy_(self.h_sizes[q], non_blocking=True)
+                self.h2d[q].record(self.s_in)
+            self._h2d_issued[q] = True
+            if self.drain:
+                with torch.cuda.stream(self.s_out):
+                    self.h_u8[q].copy_(self.u8[q], non_blocking=True)
+                    self.d2h[q].record(self.s_out)
+            self._launched[p] = True
+            return
         if self.mode == 'graph':
             if self.graphs[p] is None:
                 self._capture(p)
             self.graphs[p].replay()
         else:       # the two copies on streams of their own (fork / join by events) beside this batch's compute: the generator's own hipGraph
             gen = self.model.generator          # replay ('replay') or its ~270 plain launches ('streams')
-            keep = (gen.use_graph, gen.defer_range_check)
+            keep = (gen.use_graph, gen.defer_range_check, getattr(gen, 'split_batch', None))
             gen.use_graph, gen.defer_range_check = self.mode == 'replay', True
+            if self.one_part:
+                gen.split_batch = 1
             try:
                 self._body(p)
             finally:
-                gen.use_graph, gen.defer_range_check = keep
+                gen.use_graph, gen.defer_range_check = keep[:2]
+                if self.one_part:
+                    gen.split_batch = keep[2]
         self.done[p].record(torch.cuda.current_stream(self.device))
         self._launched[p] = True
 
@@ -346,6 +450,10 @@ class HostFedStep:
         """Host: until the most recent launch(p) is complete (its H2D has read host set 1-p, its D2H has filled result(1-p))."""
         if self.on_gpu and self._launched[p]:
             self.done[p].synchronize()
+            if self.mode == 'host':                      # ... and the copies that launch queued on the copy streams
+                self.h2d[1 - p].synchronize()
+                if self.drain:
+                    self.d2h[1 - p].synchronize()
 
     def flush(self, p: int):
         """D2H of u8[p] (the last launch's own result: nothing follows to carry it) and a host wait for it."""
@@ -353,6 +461,9 @@ class HostFedStep:
             self.h_u8[p].copy_(self.u8[p], non_blocking=self.on_gpu)
         if self.on_gpu:
             torch.cuda.current_stream(self.device).synchronize()
+            if self.mode == 'host':
+                self.s_in.synchronize()
+                self.s_out.synchronize()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -415,7 +526,7 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
 
     def submit_loads(r):
         if r < len(rounds) and r not in loads:
-            loads[r] = [pool.submit(load_item, *items[i], pad_mod) for i in rounds[r]['batches'][rank]]
+            loads[r] = [pool.submit(load_item_u8, *items[i]) for i in rounds[r]['batches'][rank]]      # decode only: / 255, padding, mask > 0 run on the device
 
     def write_round(rd, host):
         """Rank 0: queue the PNG writes of one round from its u8 results on the host (``host`` = [ranks * batch_size, Hp, Wp, 3])."""
@@ -438,7 +549,7 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         while r1 < len(rounds) and rounds[r1]['shape'] == (Hp, Wp):
             r1 += 1
         K = r1 - r0
-        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1))
+        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS))
         gathered = h_out = None
         if world > 1 and rank == 0:
             gathered = [torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device) for _ in range(2)]
@@ -447,12 +558,12 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         collected = [torch.cuda.Event() for _ in range(2)] if (on_gpu and world > 1) else None
 
         def fill(pp, r):
-            img_np, mask_np = hs.host(pp)
             loaded = [f.result() for f in loads.pop(r)]
-            for j, x in enumerate(loaded):
-                img_np[j], mask_np[j] = x[0], x[1]
-            img_np[len(loaded):] = 0.0                                                # partial (or, for a rank without a batch, empty) round: zero padding
-            mask_np[len(loaded):] = 0.0
+            for j in range(batch_size):                                               # partial (or, for a rank without a batch, empty) round: empty slots
+                if j < len(loaded):
+                    hs.put(pp, j, loaded[j][0], loaded[j][1])
+                else:
+                    hs.put(pp, j, None, None)
 
         def collect(pp):
             """Several ranks: the round that launch(pp) just computed goes through the gather (side stream, behind the step); rank 0 downloads it."""
@@ -597,10 +708,14 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             dist.destroy_process_group()
         print(f'rank {rank}: wrote {n} refined images to {cfg["outdir"]}')
         return 0
+    import time
+    t0 = time.perf_counter()
     n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
-                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist)
+                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist, io_threads=int(cfg['io_threads']))
+    dt = time.perf_counter() - t0
     if rank == 0:
-        print(f'wrote {n} images to {cfg["outdir"]}')
+        # (the loop's own wall time: plan build + graph capture of every shape bucket, PNG decode, upload, compute, download, PNG encode + write)
+        print(f'wrote {n} images to {cfg["outdir"]} in {dt:.3f} s ({n / max(dt, 1e-9):.1f} images/s, {world} rank(s), io_threads={int(cfg["io_threads"])})')
     if world > 1:
         dist.destroy_process_group()
     return 0

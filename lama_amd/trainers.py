@@ -45,6 +45,13 @@ class DefaultInpaintingTrainingModule(nn.Module):
             raise NotImplementedError('inference only')
         return super().train(False)
 
+    def load_state_dict(self, *a, **kw):
+        # nn.Module.load_state_dict fills the children through _load_from_state_dict, not through THEIR load_state_dict: the generator's packed
+        # weights (BatchNorm folded, MFMA fragment order) must be dropped here, or a second load after a forward would keep computing with the first
+        if hasattr(self.generator, '_invalidate'):
+            self.generator._invalidate()
+        return super().load_state_dict(*a, **kw)
+
     def on_load_checkpoint(self, state):   # Lightning hook called by load_checkpoint; nothing to restore
         pass
 
@@ -76,6 +83,38 @@ class DefaultInpaintingTrainingModule(nn.Module):
         batch['inpainted'] = out
         batch['mask_for_losses'] = batch['mask']                                 # default.py:82-84
         return batch
+
+
+    def forward_u8(self, image_hwc: torch.Tensor, mask: torch.Tensor, sizes, out_u8: torch.Tensor, binarize: bool = True) -> torch.Tensor:
+        """The predict step of bin/predict.py:82-92 on what is on disk (round 6, ABI v110): ``image_hwc`` u8 [B,Hp,Wp,3] and ``mask`` u8 [B,Hp,Wp]
+        hold each image's h x w pixels in the top-left corner of its slot, ``sizes`` int32 [B,2] = (h, w) on the device (None: full slots).  The
+        first launch does load_image's / 255, pad_img_to_modulo's symmetric padding and predict.py:84's mask > 0 while it composes the
+        generator's input (default.py:59,67-68); the last one blends (default.py:71) and writes predict.py:92's clipped u8 HWC image into
+        ``out_u8`` [B,Hp,Wp,3] (returned).  Bit-identical to ``forward`` on the fp32 tensors the reference's host code builds + quantize_u8_hwc."""
+        ex = self.generator._exec
+        if not ex.injected and not image_hwc.is_cuda:
+            raise L.LamaError('lama_amd runs on an MI355X only: input tensor is on ' + str(image_hwc.device) + ' (there is no CPU fallback)')
+        if image_hwc.dtype != torch.uint8 or mask.dtype != torch.uint8 or out_u8.dtype != torch.uint8:
+            raise L.LamaError('forward_u8: uint8 image / mask / output tensors')
+        B, H, W, _ = image_hwc.shape
+        if tuple(mask.shape) != (B, H, W) or tuple(out_u8.shape) != (B, H, W, 3) or not (image_hwc.is_contiguous() and mask.is_contiguous() and out_u8.is_contiguous()):
+            raise L.LamaError(f'forward_u8: image {tuple(image_hwc.shape)} / mask {tuple(mask.shape)} / out {tuple(out_u8.shape)}: contiguous [B,H,W,3], [B,H,W], [B,H,W,3]')
+        if not self.concat_mask:
+            raise NotImplementedError('concat_mask=False is not used by big-lama')
+        st = ex.stream(image_hwc)
+        gen = self.generator
+        masked = gen.input_buffer((B, 4, H, W), image_hwc.device) if hasattr(gen, 'input_buffer') else torch.empty(B, 4, H, W, device=image_hwc.device)
+        ex.lib.mask_compose_u8(image_hwc, mask, sizes, L.view(masked), B, binarize, st)
+        if hasattr(gen, 'clone_output'):
+            keep, gen.clone_output = gen.clone_output, False                       # the blend below consumes the plan's own output buffer at once
+            try:
+                pred = gen(masked)
+            finally:
+                gen.clone_output = keep
+        else:
+            pred = gen(masked)
+        ex.lib.blend_quantize_u8(image_hwc, mask, sizes, L.view(pred), out_u8, B, binarize, st)
+        return out_u8
 
 
 def get_training_model_class(kind):

@@ -439,10 +439,29 @@ def test_host_fed_step_graph_matches_plain_forward():
         u8 = torch.empty(n, H, W, 3, dtype=torch.uint8, device='cuda')
         lib.quantize_u8_hwc(L.view(out), u8, n, H, W, torch.cuda.current_stream().cuda_stream)
         want.append(u8.cpu())
-    for drain, mode in ((True, 'replay'), (False, 'replay'), (True, 'streams'), (True, 'graph'), (False, 'graph')):
-        hs = HostFedStep(model, n, H, W, 'cuda', drain=drain, mode=mode)
+    # round 6: the step is fed with u8 HWC images as they are on disk (u8_input, the default) -- here with an UNPADDED 125 x 157 image in each
+    # 128 x 160 slot: / 255, the symmetric padding and mask > 0 run on the device and must equal the host's (O.load_image / pad_img_to_modulo)
+    hv, wv = H - 3, W - 3
+    raw = [dict(image=(b['image'][:, :, :hv, :wv] * 255).round().to(torch.uint8).permute(0, 2, 3, 1).contiguous().numpy(),
+                mask=(b['mask'][:, 0, :hv, :wv] * 255).round().to(torch.uint8).numpy()) for b in batches]
+    want_u8 = []
+    for r in raw:
+        im = np.stack([O.pad_img_to_modulo(np.transpose(x, (2, 0, 1)).astype('float32') / 255, 8) for x in r['image']])
+        mk = np.stack([O.pad_img_to_modulo(x[None].astype('float32') / 255, 8) for x in r['mask']])
+        out = model(dict(image=torch.from_numpy(im).cuda(), mask=(torch.from_numpy(mk).cuda() > 0) * 1))['inpainted']
+        u8 = torch.empty(n, H, W, 3, dtype=torch.uint8, device='cuda')
+        lib.quantize_u8_hwc(L.view(out), u8, n, H, W, torch.cuda.current_stream().cuda_stream)
+        want_u8.append(u8.cpu())
+    for drain, mode, u8_in in ((True, 'replay', False), (False, 'replay', False), (True, 'streams', False), (True, 'graph', False), (False, 'graph', False),
+                               (True, 'replay', True), (True, 'graph', True), (False, 'graph', True), (True, 'host', True), (False, 'host', True), (True, 'host', False)):
+        hs = HostFedStep(model, n, H, W, 'cuda', drain=drain, mode=mode, u8_input=u8_in)
+        assert hs.u8_input == u8_in
 
         def fill(p, k):
+            if u8_in:
+                for j in range(n):
+                    hs.put(p, j, raw[k]['image'][j], raw[k]['mask'][j])
+                return
             im, mk = hs.host(p)
             im[:] = batches[k]['image'].numpy()
             mk[:] = batches[k]['mask'].numpy()
@@ -465,7 +484,7 @@ def test_host_fed_step_graph_matches_plain_forward():
             got[steps - 1] = torch.from_numpy(hs.result((steps - 1) & 1).copy())
         assert sorted(got) == list(range(steps))
         for k in range(steps):
-            assert torch.equal(got[k], want[k]), (drain, mode, k)
+            assert torch.equal(got[k], (want_u8 if u8_in else want)[k]), (drain, mode, u8_in, k)
         assert (hs.graphs[0] is not None and hs.graphs[1] is not None) == (mode == 'graph')
     assert model.generator.check_range('cuda') is True and model.generator.use_graph is True
 

@@ -388,6 +388,9 @@ def test_range_flag_device_key_and_stale_flag(monkeypatch):
     gen.defer_range_check = False
     y = gen(x)                                                # self-checking forward of an in-range input: no LamaRangeError, no fallback
     assert gen.precision == L.PREC_F16X3 and torch.isfinite(y).all()
+    # ... but the deferred forward's report is not lost either: the self-checking scope kept it as a sticky bit for the next check_range
+    with pytest.raises(L.LamaRangeError):
+        gen.check_range('cpu')
     assert gen.check_range('cpu') is True
     with pytest.raises(L.LamaRangeError):
         gen(xb)                                               # ... and it still catches its own
@@ -454,7 +457,7 @@ def test_host_fed_step_double_buffering():
         u8 = torch.empty(n, H, W, 3, dtype=torch.uint8)
         lib.quantize_u8_hwc(L.view(out), u8, n, H, W, 0)
         want.append(u8)
-    hs = HostFedStep(model, n, H, W, 'cpu', drain=True)
+    hs = HostFedStep(model, n, H, W, 'cpu', drain=True, u8_input=False)
 
     def fill(p, k):
         im, mk = hs.host(p)
@@ -536,6 +539,7 @@ def test_split_batch_plan_is_bit_identical(small):
         return real(*a, **kw)
 
     try:
+        gen._plans.clear()                                   # (plans of other shapes the shared fixture's earlier tests left)
         assert gen._split_parts(x.shape, x.device) == 1
         y1 = gen(x).clone()
         assert 'parts' not in next(iter(gen._plans.values()))
@@ -558,3 +562,52 @@ def test_split_batch_plan_is_bit_identical(small):
         gen._exec.lib.conv2d = real
         gen.split_batch = None
         gen._plans.clear()
+
+
+def test_host_fed_step_u8_input_equals_the_host_conversion():
+    """Round 6 (ABI v110): HostFedStep fed with u8 HWC images as they are on disk -- unpadded 29 x 37 images in 32 x 40 slots, a gray mask, an empty
+    slot of a partial batch -- against the reference's host-side conversion (load_image's / 255, pad_img_to_modulo, mask > 0: oracle) + the
+    module's forward + quantize_u8_hwc: the same bytes."""
+    from lama_amd import _lib as L
+    from lama_amd.predict import HostFedStep
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = {'generator.' + k: v for k, v in O.make_synthetic_state_dict(cfg, seed=11, calib_hw=32).items()}
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
+    model.load_state_dict(sd, strict=True)
+    model.freeze()
+    model.generator.set_exec(F._Exec(emu_lib()))
+    lib = model.generator._exec.lib
+    n, H, W, hv, wv, steps = 2, 32, 40, 29, 37, 3
+    g = torch.Generator().manual_seed(5)
+    raw = [dict(image=torch.randint(0, 256, (hv, wv, 3), generator=g, dtype=torch.uint8).numpy(),
+                mask=(torch.randint(0, 3, (hv, wv), generator=g) * 100).to(torch.uint8).numpy()) for _ in range(steps)]       # mask values 0 / 100 / 200
+    want = []
+    for r in raw:
+        im = O.pad_img_to_modulo(np.transpose(r['image'], (2, 0, 1)).astype('float32') / 255, 8)[None]
+        mk = O.pad_img_to_modulo(r['mask'][None].astype('float32') / 255, 8)[None]
+        out = model(dict(image=torch.from_numpy(im), mask=(torch.from_numpy(mk) > 0) * 1))['inpainted']
+        u8 = torch.empty(1, H, W, 3, dtype=torch.uint8)
+        lib.quantize_u8_hwc(L.view(out), u8, 1, H, W, 0)
+        want.append(u8[0])
+    hs = HostFedStep(model, n, H, W, 'cpu', drain=True)
+    assert hs.u8_input
+
+    def fill(p, k):
+        hs.put(p, 0, raw[k]['image'], raw[k]['mask'])
+        hs.put(p, 1, None, None)                          # the empty slot of a partial batch
+
+    got = {}
+    fill(0, 0)
+    hs.prime(0)
+    for k in range(steps):
+        p = k & 1
+        if k + 1 < steps:
+            fill(1 - p, k + 1)
+        hs.launch(p)
+        if k >= 1:
+            hs.wait(p)
+            got[k - 1] = torch.from_numpy(hs.result(1 - p).copy())
+    hs.flush((steps - 1) & 1)
+    got[steps - 1] = torch.from_numpy(hs.result((steps - 1) & 1).copy())
+    for k in range(steps):
+        assert torch.equal(got[k][0], want[k]), k

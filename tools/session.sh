@@ -33,9 +33,9 @@ d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r, f = d.get('roofline') or {}, d.get('roofline_ffc') or {}
 print('bench:', d['value'], d['unit'], d['ms_per_step'], 'ms | roofline', r.get('kernel'), r.get('achieved'), 'TF frac', r.get('frac'),
       '| ffc', f.get('avg_us'), 'us frac', f.get('frac'), 'traffic', f.get('traffic'))
-for k in ('pytorch_rocm_eager', 'exact_f32_leg', 'cpu_baseline', 'configs2_fp16_leg', 'configs4_refine_leg', 'value_host_fed', 'batch16_leg'):
+for k in ('pytorch_rocm_eager', 'exact_f32_leg', 'cpu_baseline', 'configs2_fp16_leg', 'configs4_refine_leg', 'configs4_refine_default_leg', 'photo_leg', 'predict_cli_leg', 'value_host_fed', 'batch16_leg'):
     if d.get(k):
-        print(' ', k, json.dumps(d[k])[:220])
+        print(' ', k, json.dumps(d[k])[:1500])
 print('  kernels_us:', json.dumps(d.get('kernels_us'))[:1200])
 PY
 }

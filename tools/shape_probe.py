@@ -32,6 +32,8 @@ def main():
     timer = bench.KernelTimer(lib) if os.environ.get('PROBE_KERNELS') else None
     model = bench.build_model(device, L.PREC_NAMES[os.environ.get('PROBE_PREC', 'f16x3')])
     model.keep_predicted_image = False
+    if 'PROBE_OVERLAP' in os.environ:          # 0: every layer's launches on ONE stream (no spectral branch beside the local conv)
+        model.generator.overlap_streams = bool(int(os.environ['PROBE_OVERLAP']))
     st = torch.cuda.current_stream().cuda_stream
     for (b, h, w) in shapes:
         img, mask = batch_of(b, h, w, device)
