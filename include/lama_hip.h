@@ -142,15 +142,20 @@ int lama_conv2d_fwd(void* stream, const lama_conv2d_args* args);
  * multiplies per 2 x 2 output tile and (output, input) channel pair -- the launch is bound by the power the matrix cores draw, so
  * fewer MFMA products is what shortens it.  Split precisions only (LAMA_PREC_F16X3 / BF16X3; the 3-term split is applied to the
  * transformed operands: 1.2e-5 max-abs end to end with every such conv of the generator in this form); fp32 tensors; Cin % 32 == 0,
- * Cout % 128 == 0, W in {32, 64, 128, 256}, H a multiple of 512 / W.  Anything else: LAMA_ERR_UNSUPPORTED (use lama_conv2d_fwd).
+ * Cout % 128 == 0, H >= 4, W >= 8 (v110: any plane size -- tile rows are cut into overlapping segments of 8 / 16 / 32 column quads and the
+ * columns behind W - 1 inside the last quad are reflected in registers; W in {32, 64, 128, 256} with H a multiple of 512 / W keep the exact
+ * geometry of v107).  Anything else: LAMA_ERR_UNSUPPORTED (use lama_conv2d_fwd).
  *   lama_winograd_pack_weight: Conv2d weights [Cout, Cin, 3, 3] -> U = G g G^T per channel pair, BatchNorm scale folded, (hi, lo)
  *     split, MFMA A-fragment order; lama_winograd_packed_weight_bytes bytes.
  *   lama_winograd_conv3x3_fwd: args as lama_conv2d_fwd (x, w_packed, bias, act, resid, y, batch, precision, range_flag; kh = kw = 3,
  *     stride = 1, pad = 1, pad_mode = LAMA_PAD_REFLECT, or (v108) LAMA_PAD_ZERO: the dgrad convs of the reverse pass); workspace = lama_winograd_workspace_bytes device bytes (the half-inverted
- *     transform-domain sums between its two launches).  x, y, resid: 16-byte aligned pointers, batch strides multiples of 4 elements
- *     (else LAMA_ERR_UNSUPPORTED).
+ *     transform-domain sums between its two launches).  The exact geometries want x, y, resid as 16-byte aligned pointers with batch strides
+ *     that are multiples of 4 elements (else LAMA_ERR_UNSUPPORTED); the any-size geometry needs element alignment only.
  *   lama_winograd_supported: 1 when lama_winograd_conv3x3_fwd takes this (cout, cin, H, W, precision) -- every bound of the launch,
  *     including the 32-bit byte offsets inside one image (cin * H * W * 4 < 2^31), which the workspace query alone does not see.
+ *   lama_winograd_preferred (v110): 1 when this form is expected to beat lama_conv2d_fwd for (batch, cout, cin, H, W) -- always for the exact
+ *     geometries; for the any-size geometry a cost model of whole rounds of workgroups (one per CU) against the direct kernel's: a launch of a
+ *     little more than 256 units takes two rounds and loses (1 x 135 x 240), one of a little less wins (1 x 168 x 168: 65 against 92 us).
  *   range_flag (LAMA_PREC_F16X3): NOT the same watch as lama_conv2d_fwd's.  It is kept on the row sums r of the input transform
  *     (|V| <= 2 max|r|) and is raised at 2 max|r| >= 65504, i.e. up to 2x EARLY against a real overflow of a transformed operand, and it
  *     is BLIND TO NaN inputs (fmaxf drops them).  Inside the generator the global-branch launch (lama_conv2d_fwd) reads the same state
@@ -158,6 +163,7 @@ int lama_conv2d_fwd(void* stream, const lama_conv2d_args* args);
  *     check (or lama_conv2d_fwd) on x. */
 int64_t lama_winograd_packed_weight_bytes(int32_t cout, int32_t cin, int32_t precision);
 int32_t lama_winograd_supported(int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t precision);
+int32_t lama_winograd_preferred(int32_t batch, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t precision);
 int lama_winograd_pack_weight(void* stream, const float* w, const float* scale, int32_t cout, int32_t cin, int32_t precision, void* dst);
 size_t lama_winograd_workspace_bytes(int32_t batch, int32_t cout, int32_t H, int32_t W);
 int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* args, void* workspace, size_t workspace_bytes);

@@ -149,6 +149,7 @@ class LamaLib:
         L.lama_winograd_pack_weight.restype, L.lama_winograd_pack_weight.argtypes = C.c_int, [vp, vp, vp, i32, i32, i32, vp]
         L.lama_winograd_workspace_bytes.restype, L.lama_winograd_workspace_bytes.argtypes = C.c_size_t, [i32, i32, i32, i32]
         L.lama_winograd_supported.restype, L.lama_winograd_supported.argtypes = i32, [i32, i32, i32, i32, i32]
+        L.lama_winograd_preferred.restype, L.lama_winograd_preferred.argtypes = i32, [i32, i32, i32, i32, i32, i32]
         L.lama_winograd_conv3x3_fwd.restype, L.lama_winograd_conv3x3_fwd.argtypes = C.c_int, [vp, C.POINTER(Conv2dArgs), vp, C.c_size_t]
         del dp
         if L.lama_version() != ABI_VERSION:
@@ -224,6 +225,10 @@ class LamaLib:
     def winograd_supported(self, cout: int, cin: int, H: int, W: int, precision: int) -> bool:
         return (precision in (PREC_F16X3, PREC_BF16X3) and self._l.lama_winograd_packed_weight_bytes(cout, cin, precision) > 0
                 and self._l.lama_winograd_supported(cout, cin, H, W, precision) == 1)
+
+    def winograd_preferred(self, batch: int, cout: int, cin: int, H: int, W: int, precision: int) -> bool:
+        """(v110) supported AND expected to beat the direct kernel at this batch (the any-size geometry pays for whole rounds of workgroups)."""
+        return self.winograd_supported(cout, cin, H, W, precision) and self._l.lama_winograd_preferred(batch, cout, cin, H, W, precision) == 1
 
     def winograd_workspace_bytes(self, batch: int, cout: int, H: int, W: int) -> int:
         return int(self._l.lama_winograd_workspace_bytes(batch, cout, H, W))

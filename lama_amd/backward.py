@@ -237,7 +237,7 @@ class RearPass:
         nws = self.ex.lib.fft_workspace_bytes(B, half, H, W)
         lib = self.ex.lib
         nwino = 0
-        if self.ex.winograd and lib.winograd_supported(f0.out_cl, f0.in_cl + f0.in_cg, H, W, self.gen.precision):
+        if self.ex.winograd and lib.winograd_preferred(B, f0.out_cl, f0.in_cl + f0.in_cg, H, W, self.gen.precision):
             nwino = lib.winograd_workspace_bytes(B, f0.out_cl, H, W)
         sh = dict(s1=e(B, 2 * half, H, wf), s3=e(B, 2 * half, H, wf), t=e(B, half, H, W),
                   fftws=(e(nws // 4 + 1) if nws else None), wino=(e(nwino // 4) if nwino else None),
@@ -245,7 +245,7 @@ class RearPass:
                   gp_l=e(B, f0.in_cl, H + 2, W + 2), gp_g=e(B, f0.in_cg, H + 2, W + 2), g_t=e(B, half, H, W), g_x1=e(B, half, H, W),
                   g1=e(B, f0.in_cg, H, W))
         if (self.ex.winograd and self.bprec in (L.PREC_BF16X3, L.PREC_F16X3) and f0.in_cl % 128 == 0
-                and lib.winograd_supported(f0.in_cl, f0.out_cl + f0.out_cg, H, W, self.bprec)):
+                and lib.winograd_preferred(B, f0.in_cl, f0.out_cl + f0.out_cg, H, W, self.bprec)):
             # the dgrad into x_l as Winograd interior + frame (its own workspace: gm of the layer is live while the forward one is not, but
             # the split-K factor differs with the channel counts)
             sh['wino_b'] = e(lib.winograd_workspace_bytes(B, f0.in_cl, H, W) // 4)

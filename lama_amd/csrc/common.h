@@ -148,6 +148,7 @@ LAMA_CB_DECL(_f16)
     int lama_cb_wino_pack_weight##sfx(hipStream_t stream, const float* w, const float* scale, int cout, int cin, void* dst);         \
     int64_t lama_cb_wino_workspace_bytes##sfx(int batch, int cout, int H, int W);                                                    \
     bool lama_cb_wino_shape_ok##sfx(int cout, int cin, int H, int W);                                                                \
+    bool lama_cb_wino_preferred##sfx(int batch, int cout, int cin, int H, int W);                                                    \
     int lama_cb_wino_fwd##sfx(hipStream_t stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes);                \
     int lama_cb_wino_out_params##sfx(const lama_conv2d_args* a, void* workspace, size_t workspace_bytes, void* out);                  \
     int lama_cb_wino_out_fwd##sfx(hipStream_t stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes);

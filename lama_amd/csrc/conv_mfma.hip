@@ -496,6 +496,13 @@ extern "C" int32_t lama_winograd_supported(int32_t cout, int32_t cin, int32_t H,
     return lama_cb_wino_shape_ok_f16x3(cout, cin, H, W) ? 1 : 0;                  // the same for both split precisions
 }
 
+// (v110) 1 when the Winograd form of this launch is expected to beat lama_conv2d_fwd (always for the exact geometries; a cost model of whole
+// rounds of workgroups for the any-size geometry of round 6: wino_dev.inc), 0 otherwise or when unsupported
+extern "C" int32_t lama_winograd_preferred(int32_t batch, int32_t cout, int32_t cin, int32_t H, int32_t W, int32_t precision) {
+    if ((precision != LAMA_PREC_F16X3 && precision != LAMA_PREC_BF16X3) || batch <= 0) return 0;
+    return lama_cb_wino_preferred_f16x3(batch, cout, cin, H, W) ? 1 : 0;
+}
+
 extern "C" int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* a, void* workspace, size_t workspace_bytes) {
     if (!a || !tensor_ok(a->x) || !tensor_ok(a->y) || !a->w_packed || a->batch <= 0) return LAMA_ERR_BAD_ARG;
     if (a->kh != 3 || a->kw != 3 || a->stride != 1 || a->pad != 1 || (a->pad_mode != LAMA_PAD_REFLECT && a->pad_mode != LAMA_PAD_ZERO) || a->transposed)
@@ -504,10 +511,8 @@ extern "C" int lama_winograd_conv3x3_fwd(void* stream, const lama_conv2d_args* a
     if (a->x.dtype != LAMA_DT_F32 || a->y.dtype != LAMA_DT_F32 || (a->resid.ptr && a->resid.dtype != LAMA_DT_F32)) return LAMA_ERR_UNSUPPORTED;
     if (a->x.H != a->y.H || a->x.W != a->y.W || a->x.H < 2 || a->x.W < 2) return LAMA_ERR_BAD_ARG;
     if (a->resid.ptr && (a->resid.C != a->y.C || a->resid.H != a->y.H || a->resid.W != a->y.W)) return LAMA_ERR_BAD_ARG;
-    // 16-byte loads / stores on x, y and resid: views that are not 16-byte aligned (pointer or batch stride) keep lama_conv2d_fwd
-    if ((((uintptr_t)a->x.ptr | (uintptr_t)a->y.ptr | (uintptr_t)a->resid.ptr) & 15) != 0 || a->x.batch_stride % 4 != 0 || a->y.batch_stride % 4 != 0 ||
-        (a->resid.ptr && a->resid.batch_stride % 4 != 0))
-        return LAMA_ERR_UNSUPPORTED;
+    // (the exact geometries -- W in {32, 64, 128, 256} -- use 16-byte loads / stores on x, y and resid and want 16-byte aligned views: checked with
+    // the geometry in lama_cb_wino_fwd; the any-size geometry of round 6 needs element alignment only)
     if (a->precision == LAMA_PREC_BF16X3) return lama_cb_wino_fwd_bf16x3((hipStream_t)stream, a, workspace, workspace_bytes);
     if (a->precision == LAMA_PREC_F16X3) return lama_cb_wino_fwd_f16x3((hipStream_t)stream, a, workspace, workspace_bytes);
     return LAMA_ERR_UNSUPPORTED;
@@ -520,8 +525,6 @@ static int wino_args_ok(const lama_conv2d_args* a) {
     if (a->y.dtype != LAMA_DT_F32 || (a->resid.ptr && a->resid.dtype != LAMA_DT_F32)) return LAMA_ERR_UNSUPPORTED;
     if (a->x.H != a->y.H || a->x.W != a->y.W) return LAMA_ERR_BAD_ARG;
     if (a->resid.ptr && (a->resid.C != a->y.C || a->resid.H != a->y.H || a->resid.W != a->y.W)) return LAMA_ERR_BAD_ARG;
-    if ((((uintptr_t)a->y.ptr | (uintptr_t)a->resid.ptr) & 15) != 0 || a->y.batch_stride % 4 != 0 || (a->resid.ptr && a->resid.batch_stride % 4 != 0))
-        return LAMA_ERR_UNSUPPORTED;
     if (a->precision != LAMA_PREC_BF16X3 && a->precision != LAMA_PREC_F16X3) return LAMA_ERR_UNSUPPORTED;
     return LAMA_OK;
 }

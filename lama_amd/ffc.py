@@ -612,7 +612,7 @@ class FFC(_HipModule):
         sc = dict(x1=x1, t=x1 if alias_t else torch.empty_like(x1), ws=self.convg2g.fu.workspace(x1))
         lib = self._exec.lib
         if (self._exec.winograd and self.kernel_size == 3 and self.stride == 1 and self.padding == 1 and self.out_cl
-                and lib.winograd_supported(self.out_cl, self.in_cl + self.in_cg, H, W, self.precision)):
+                and lib.winograd_preferred(B, self.out_cl, self.in_cl + self.in_cg, H, W, self.precision)):
             sc['wino'] = torch.empty(lib.winograd_workspace_bytes(B, self.out_cl, H, W) // 4, device=device, dtype=torch.float32)
         return sc
 

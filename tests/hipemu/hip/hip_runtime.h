@@ -288,7 +288,10 @@ static inline unsigned hipemu_buf_load_b32(lama_buf_t r, unsigned voff, unsigned
 static inline hipemu_u32x4 hipemu_buf_load_b128(lama_buf_t r, unsigned voff, unsigned soff) {
     unsigned long long o = (unsigned long long)voff + soff;
     hipemu_u32x4 v = {0, 0, 0, 0};
-    if (o + 16 <= r.n) memcpy(&v, r.p + o, 16);
+    // raw buffers are range-checked per DWORD (a 16-byte load that straddles the end returns its in-range dwords, zeros behind them): the
+    // any-size Winograd staging reads the plane's last quad of the last channel this way (tests/test_kernels_gpu.py checks the hardware against it)
+    for (int d = 0; d < 4; ++d)
+        if (o + 4 * d + 4 <= r.n) { unsigned t; memcpy(&t, r.p + o + 4 * d, 4); v[d] = t; }
     return v;
 }
 static inline void hipemu_buf_store_b32(lama_buf_t r, unsigned v, unsigned voff, unsigned soff) {

@@ -503,15 +503,24 @@ WINO_CASES = [
     dict(cin=64, cout=128, H=16, W=64, B=2, act=0, bias=False, resid=False, scale=False),
     dict(cin=32, cout=256, H=8, W=64, B=1, act=1, bias=True, resid=False, scale=True),
     dict(cin=128, cout=128, H=16, W=32, B=1, act=1, bias=True, resid=True, scale=True),       # 8 (band, xi) units: the input channels dealt to four workgroups each (split-K of small launches)
+    # round 6: any plane size -- tile rows cut into overlapping segments of 8 / 16 / 32 column quads, reflected columns inside the last quad, odd heights
+    dict(cin=32, cout=128, H=9, W=30, B=1, act=1, bias=True, resid=True, scale=True),         # one segment of 8 quads, W % 4 = 2, odd H
+    dict(cin=32, cout=128, H=10, W=37, B=2, act=0, bias=True, resid=False, scale=False),      # two segments, W % 4 = 1 (the reflected column is the left neighbour's)
+    dict(cin=32, cout=128, H=7, W=43, B=1, act=1, bias=False, resid=True, scale=True),        # W % 4 = 3
+    dict(cin=32, cout=128, H=6, W=68, B=1, act=1, bias=True, resid=True, scale=False),        # three segments of 8 quads for 17
+    dict(cin=32, cout=128, H=4, W=136, B=1, act=1, bias=True, resid=False, scale=True, qr=16),  # forced 16-quad segments: three for 34
+    dict(cin=32, cout=128, H=4, W=136, B=1, act=0, bias=False, resid=True, scale=False, qr=32), # forced 32-quad segments: two for 34
 ]
 
 
 @pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
 @pytest.mark.parametrize('case', WINO_CASES, ids=lambda c: f"c{c['cin']}o{c['cout']}_{c['H']}x{c['W']}b{c['B']}")
-def test_winograd_conv3x3_emulated(case, prec):
+def test_winograd_conv3x3_emulated(case, prec, monkeypatch):
     """lama_winograd_conv3x3_fwd against the plain torch conv (reflect pad 1) -- the same function as lama_conv2d_fwd on this layer --
     and against the direct HIP kernel on the same inputs."""
     lib = emu_lib()
+    if case.get('qr'):
+        monkeypatch.setenv('LAMA_WG_QR', str(case['qr']))
     g = torch.Generator().manual_seed(5)
     B, cin, cout, H, W = case['B'], case['cin'], case['cout'], case['H'], case['W']
     x = torch.randn(B, cin + 2, H, W, generator=g)[:, 1:1 + cin]            # a channel slice of a wider buffer
@@ -523,7 +532,7 @@ def test_winograd_conv3x3_emulated(case, prec):
     ref0 = _conv_ref(x, w, 1, 1, True, False, None, 0, None, scale=scale)
     resid = torch.randn(ref0.shape, generator=g) if case['resid'] else None
     ref = _conv_ref(x, w, 1, 1, True, False, bias, case['act'], resid, scale=scale)
-    assert lib.winograd_supported(cout, cin, H, W, prec) and not lib.winograd_supported(cout, cin, H, 48, prec)
+    assert lib.winograd_supported(cout, cin, H, W, prec) and not lib.winograd_supported(cout, cin, 3, W, prec) and not lib.winograd_supported(cout, cin, H, 6, prec)
     assert not lib.winograd_supported(cout, cin, H, W, L.PREC_F32) and not lib.winograd_supported(96, cin, H, W, prec)
     wp = lib.pack_winograd_weight(w, scale, prec)
     ws = torch.zeros(lib.winograd_workspace_bytes(B, cout, H, W) // 4)

@@ -673,7 +673,13 @@ def test_rfft2_irfft2_fp16_io(lib, hw):
 @pytest.mark.parametrize('prec', [L.PREC_BF16X3, L.PREC_F16X3], ids=['bf16x3', 'f16x3'])
 @pytest.mark.parametrize('case', WINO_CASES + [dict(cin=512, cout=128, H=64, W=64, B=8, act=1, bias=True, resid=True, scale=True),
                                                dict(cin=512, cout=128, H=128, W=128, B=2, act=1, bias=True, resid=True, scale=True),
-                                               dict(cin=64, cout=128, H=32, W=256, B=1, act=0, bias=False, resid=False, scale=False)],
+                                               dict(cin=64, cout=128, H=32, W=256, B=1, act=0, bias=False, resid=False, scale=False),
+                                               # round 6: the bottleneck planes of photo-sized inputs (1080 x 1920, 1344^2, 1000 x 1504, 4 x 720 x 1280)
+                                               dict(cin=512, cout=128, H=135, W=240, B=1, act=1, bias=True, resid=True, scale=True),
+                                               dict(cin=512, cout=128, H=168, W=168, B=1, act=1, bias=True, resid=True, scale=True),
+                                               dict(cin=512, cout=128, H=125, W=188, B=1, act=1, bias=True, resid=False, scale=True),
+                                               dict(cin=512, cout=128, H=90, W=160, B=4, act=1, bias=True, resid=True, scale=True),
+                                               dict(cin=64, cout=128, H=31, W=255, B=1, act=0, bias=False, resid=False, scale=False)],
                          ids=lambda c: f"c{c['cin']}o{c['cout']}_{c['H']}x{c['W']}b{c['B']}")
 def test_winograd_conv3x3(lib, case, prec):
     """lama_winograd_conv3x3_fwd (Winograd F(2x2, 3x3), wino_dev.inc) against the plain torch conv and the direct HIP kernel, incl. the
