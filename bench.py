@@ -667,6 +667,7 @@ def main():
     ap.add_argument('--split-batch', type=int, default=0, choices=[0, 1, 2, 4], help='parts of the batch as parallel branches of the hipGraph: 0 = the generator\'s rule, verified by timing once per shape (config.split_check); 1 / 2 / 4 force it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the PyTorch-ROCm eager comparator (subprocess)')
+    ap.add_argument('--no-host-fed-leg', action='store_true', help='skip the host-fed legs (profiling runs: only whole-batch launches of the one plan in the trace)')
     ap.add_argument('--no-cli-leg', action='store_true', help='skip the end-to-end python -m lama_amd.predict leg (subprocesses)')
     ap.add_argument('--no-photo-leg', action='store_true', help='skip the photo-sized-input leg')
     ap.add_argument('--lib', default=None, help='A/B runs: another build of liblama_hip.so (e.g. lama_amd/lib/liblama_hip_prof.so, whose kernel '
@@ -737,7 +738,7 @@ def main():
     # the same K steps fed from / drained to pinned HOST buffers (SURVEY.md 8(d) "includes H2D/D2H"): u8 image + mask in, u8 out,
     # copies on the compute stream (serial, not overlapped).  Reported beside `value`, never as `value`.
     dt_pcie = dt_piped = dt_piped_graph = dt_replay = dt_host = hf_mode = None
-    if world == 1:
+    if world == 1 and not args.no_host_fed_leg:
         h_img, h_mask = loop.img_u8.cpu().pin_memory(), loop.mask_u8.cpu().pin_memory()      # (round 6) what is on disk: u8 HWC image + u8 mask, 8.4 MB per step
         h_u8 = torch.empty(BATCH, RES, RES, 3, dtype=torch.uint8).pin_memory()
         d_img, d_mask = torch.empty_like(loop.img_u8), torch.empty_like(loop.mask_u8)

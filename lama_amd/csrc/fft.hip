@@ -1769,8 +1769,7 @@ int mr_plan(int n, unsigned short* rad) {
 // threads per workgroup (256, or 1024 for planes of more than 5120 elements -- four waves per SIMD at 128 registers measured a little faster than 512 threads at 256, spills of the radix-14 .. 16 passes included: profiles/r06_fft_mr.txt; 0 = the plane does not fit) and the LDS bytes of the one-pass mixed-radix kernels
 int mr_threads(int h, int w, size_t* lds) {
 #ifdef LAMA_PROFILING
-    static const int on = lama_env_int("LAMA_FFT_MR", 1);
-    if (!on) return 0;
+    { const int on = lama_env_int("LAMA_FFT_MR", 1); if (on != 1) return 0; }      // 0: the round-5 paths (A/B runs); 2: the two-launch form for every plane (tests); read per call
 #endif
     if (h < 1 || w < 2 || h > 65535 || w > 65535) return 0;
     const long long hh = (h + 1) / 2, wf = w / 2 + 1, rsw = w | 1;
@@ -1794,6 +1793,18 @@ bool mr_fill(MrParams& q, const FftParams& p, int nt) {
     for (int i = 0; i < q.ncp; ++i) if ((q.crad[i] > 16 ? p.h : p.h / q.crad[i]) > nt * (q.crad[i] > 16 ? MR_ANYE : 1)) return false;
     return true;
 }
+// the two-launch form (mr2_* kernels, 256 threads): pass lists + LDS bytes of the row / column workgroups; false when a length does not fit
+bool mr2_fill(MrParams& q, const FftParams& p, size_t* lds_rows, size_t* lds_cols) {
+#ifdef LAMA_PROFILING
+    if (lama_env_int("LAMA_FFT_MR", 1) == 0) return false;
+#endif
+    if (p.h < 1 || p.w < 2 || p.h > 65535 || p.w > 65535) return false;
+    if (!mr_fill(q, p, MR2_NT)) return false;
+    *lds_rows = ((size_t)p.w + (size_t)MR2_PAIRS * q.rsw) * sizeof(float2);
+    *lds_cols = ((size_t)p.h + (size_t)p.h * MR2_COLS) * sizeof(float2);
+    return *lds_rows <= 160 * 1024 && *lds_cols <= 160 * 1024;
+}
+
 #ifdef MR_BENCH_ONLY      // tools/ubench/mk_mr_bench.sh: one instantiation per kernel (compile time of the ablation builds)
 #define MR_GO(name, nt, lds, q) hipLaunchKernelGGL((name<MR_BENCH_ONLY, false>), dim3((q).f.nplanes), dim3(MR_BENCH_ONLY), lds, st, q)
 #else
@@ -1921,6 +1932,18 @@ static int rfft2_impl(void* stream, const lama_tensor* x, const lama_tensor* spe
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
     }
+    if (!mask) {   // any other plane: the two-launch form of the mixed-radix passes (fft_mr_dev.inc); lengths with a prime factor too large for them keep the DFT
+        MrParams q;
+        size_t ldr = 0, ldc = 0;
+        if (mr2_fill(q, p, &ldr, &ldc)) {
+            if (hf) hipLaunchKernelGGL(mr2_rows_fwd_kernel<true>, dim3(p.nplanes * lama_ceil_div((p.h + 1) / 2, MR2_PAIRS)), dim3(MR2_NT), ldr, st, q, ws);
+            else hipLaunchKernelGGL(mr2_rows_fwd_kernel<false>, dim3(p.nplanes * lama_ceil_div((p.h + 1) / 2, MR2_PAIRS)), dim3(MR2_NT), ldr, st, q, ws);
+            LAMA_CHECK_LAUNCH();
+            FFT_GO(mr2_cols_kernel, (false), dim3(p.nplanes * lama_ceil_div(p.wf, MR2_COLS)), dim3(MR2_NT), ldc, q, ws);
+            LAMA_CHECK_LAUNCH();
+            return LAMA_OK;
+        }
+    }
     long long nrows = (long long)p.nplanes * p.h;
     fft_dft_split(p);
     size_t lds1 = (size_t)p.w * sizeof(float2) + (size_t)DFT_ROWS_PER_WG * ((size_t)(p.w + p.w1) * sizeof(float2) + p.w * sizeof(float));
@@ -2022,6 +2045,18 @@ static int irfft2_impl(void* stream, const lama_tensor* spec, const lama_tensor*
         else hipLaunchKernelGGL(fft2p_rows_inv_kernel<false>, dim3(p.nplanes * lama_ceil_div(p.h / 2, FFT2P_PAIRS)), dim3(LAMA_NTHREADS), ldsr, st, p, (const float2*)ws);
         LAMA_CHECK_LAUNCH();
         return LAMA_OK;
+    }
+    if (!mask) {
+        MrParams q;
+        size_t ldr = 0, ldc = 0;
+        if (mr2_fill(q, p, &ldr, &ldc)) {
+            FFT_GO(mr2_cols_kernel, (true), dim3(p.nplanes * lama_ceil_div(p.wf, MR2_COLS)), dim3(MR2_NT), ldc, q, ws);
+            LAMA_CHECK_LAUNCH();
+            if (hf) hipLaunchKernelGGL(mr2_rows_inv_kernel<true>, dim3(p.nplanes * lama_ceil_div((p.h + 1) / 2, MR2_PAIRS)), dim3(MR2_NT), ldr, st, q, (const float2*)ws);
+            else hipLaunchKernelGGL(mr2_rows_inv_kernel<false>, dim3(p.nplanes * lama_ceil_div((p.h + 1) / 2, MR2_PAIRS)), dim3(MR2_NT), ldr, st, q, (const float2*)ws);
+            LAMA_CHECK_LAUNCH();
+            return LAMA_OK;
+        }
     }
     long long nrows = (long long)p.nplanes * p.h;
     fft_dft_split(p);

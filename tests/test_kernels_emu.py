@@ -229,6 +229,30 @@ def test_rfft2_irfft2_emulated(hw):
     assert torch.allclose(y2, ref2 - resid, atol=tol, rtol=1e-4)
 
 
+@pytest.mark.parametrize('hw', [(45, 60), (21, 94), (27, 25), (9, 14), (67, 40), (16, 24)], ids=lambda s: f'{s[0]}x{s[1]}')
+def test_rfft2_irfft2_two_launch_mixed_radix_emulated(hw, monkeypatch):
+    """Round 6: the two-launch form of the mixed-radix passes (mr2_* kernels: planes that do not fit one workgroup's LDS and are not powers of
+    two), forced here on small planes (LAMA_FFT_MR=2, profiling build)."""
+    monkeypatch.setenv('LAMA_FFT_MR', '2')
+    lib = emu_lib()
+    h, w = hw
+    g = torch.Generator().manual_seed(h * 31 + w)
+    B, Cn = 2, 3
+    wide = torch.randn(B, Cn + 2, h, w, generator=g)
+    x = wide[:, 1:1 + Cn]
+    spec = torch.zeros(B, 2 * Cn, h, w // 2 + 1)
+    ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4)
+    lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, ws)
+    assert torch.allclose(spec, _spec_ref(x), atol=3e-5, rtol=1e-4)
+    spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g))
+    resid = torch.randn(B, Cn, h, w, generator=g)
+    y = torch.zeros(B, Cn, h, w)
+    lib.irfft2(L.view(spec2), L.view(resid), L.view(y), B, ws)
+    assert torch.allclose(y, resid + _inv_ref(spec2, h, w), atol=3e-5, rtol=1e-4)
+    with pytest.raises(L.LamaError):
+        lib.rfft2(L.view(wide, 1, Cn), L.view(spec), B, None)          # this form needs the workspace
+
+
 def test_fft_masked_entries_emulated():
     """lama_rfft2_masked_fwd / lama_irfft2_masked_fwd (v108): the transform times [mask > 0] in one launch on 256 x 256 planes, LAMA_ERR_UNSUPPORTED
     (nothing launched) elsewhere."""

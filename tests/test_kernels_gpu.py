@@ -207,7 +207,7 @@ def test_conv2d_fused_second_operand_full_size(lib, prec):
     assert err < 3e-4, err
 
 
-@pytest.mark.parametrize('hw', FFT_SIZES + [(128, 128), (512, 256), (168, 168), (135, 240), (125, 188), (96, 128), (127, 131), (128, 256), (160, 120), (199, 100), (192, 256), (251, 64)], ids=lambda s: f'{s[0]}x{s[1]}')
+@pytest.mark.parametrize('hw', FFT_SIZES + [(128, 128), (512, 256), (168, 168), (135, 240), (125, 188), (96, 128), (127, 131), (128, 256), (160, 120), (199, 100), (192, 256), (251, 64), (270, 480), (375, 500), (188, 376)], ids=lambda s: f'{s[0]}x{s[1]}')
 def test_rfft2_irfft2(lib, hw):
     h, w = hw
     g = torch.Generator().manual_seed(h * 131 + w)

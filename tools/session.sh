@@ -49,9 +49,11 @@ for STEP in "$@"; do
     smoke)  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a $O/summary.txt ;;
     bench)  timeout 1200 python bench.py $ARG > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err; digest $O/bench.json | tee -a $O/summary.txt ;;
     quick)  timeout 400 python bench.py $QUICK > $O/bench_quick.json 2> $O/bench_quick.err; tail -c 300 $O/bench_quick.err; digest $O/bench_quick.json | tee -a $O/summary.txt ;;
-    stats)  # rocprofv3's kernel trace SERIALISES the queues a split plan runs on (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of
+    stats)  # (round 6: --split-batch 1 --no-host-fed-leg: every launch in the trace is a whole-batch launch of the ONE-part plan: 2 warm-up + 10 timed graph replays,
+            #  then 2 x (1 warm-up + 3 instrumented) eager steps = 20 steps, i.e. 35 x 20 = 700 calls of the fused global launch)
+            # rocprofv3's kernel trace SERIALISES the queues a split plan runs on (profiles/r05_overlap_under_rocprof.txt: 33 ms per replay instead of
             # 9.4): the generator's own check (verify_split) sees that and keeps the one-part plan -- the same kernels over the whole batch
-            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/prof_bench.log 2>&1)
+            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$O/prof -o bench -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg --no-host-fed-leg --split-batch 1 > $ROOT/$O/prof_bench.log 2>&1)
             grep -o '"value": [0-9.]*, "unit": "images/s", "n_gpus"' $O/prof_bench.log | head -1 | tee -a $O/summary.txt; grep -o '"ms_per_step": [0-9.]*' $O/prof_bench.log | head -1 | tee -a $O/summary.txt; grep -o '"split_batch": [^}]*}' $O/prof_bench.log | head -1 | tee -a $O/summary.txt
             for db in $(find $O/prof -name '*.db' | head -1); do python tools/rocpd_summary.py $db $O/kernel_stats.csv; python tools/timeline.py $db $O/timeline.txt 0; done
             rm -rf $O/prof; head -16 $O/kernel_stats.csv | cut -c1-170 | tee -a $O/summary.txt ;;
@@ -64,7 +66,7 @@ for STEP in "$@"; do
             rm -rf $O/prof_split; tail -2 $O/prof_split.log | tee -a $O/summary.txt ;;
     pmc)    bash tools/pmc_session.sh $TAG/pmc_$(echo $ARG | tr ' ' '_') "f16x3 $ARG" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT" 2>&1 | tail -40 | tee -a $O/summary.txt ;;
     pmcbench) for CNT in FETCH_SIZE WRITE_SIZE; do
-              (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg > $ROOT/$O/pmcb_$CNT.log 2>&1)
+              (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg --no-host-fed-leg --split-batch 1 > $ROOT/$O/pmcb_$CNT.log 2>&1)
               f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f > $O/pmc_bench_$CNT.txt && grep -E "conv_wr_kernel|wino_|gemm1x1_wk|fft2_ip64|convt2|head7|stem7" $O/pmc_bench_$CNT.txt | cut -c1-60,118-200 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done
               python tools/pmc_bench_to_json.py $O/pmc.json $O/pmc_bench_FETCH_SIZE.txt $O/pmc_bench_WRITE_SIZE.txt | tee -a $O/summary.txt ;;
     shapes) for cfg in "4 1024" "4 256" "1 512" "1 2048"; do set -- $cfg
