@@ -62,6 +62,8 @@ CONV_CASES = [
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=0, bias=False, resid=False, scale=False, transposed=True, ct=0),
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=2, bias=True, resid=False, scale=True, transposed=True),            # sigmoid: not convt2_kernel's epilogue -> the fused LDS-staged launch
+    dict(cin=32, cout=64, k=3, stride=2, pad=1, H=5, W=37, act=1, bias=True, resid=False, scale=True, transposed=True),            # round 6: convt2_kernel with ragged last tiles (H % 4, W % 32 != 0)
+    dict(cin=64, cout=64, k=3, stride=2, pad=1, H=6, W=70, act=0, bias=False, resid=False, scale=False, transposed=True, ct_grid=2),
     dict(cin=128, cout=64, k=3, stride=2, pad=1, H=12, W=32, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=2),  # up3's channel counts: 8 sub-chunks, 6 tiles on 2 workgroups
     dict(cin=64, cout=128, k=3, stride=2, pad=1, H=8, W=64, act=1, bias=True, resid=False, scale=True, transposed=True, ct_grid=3),   # 16 tiles on 3 persistent workgroups
     # ... stride 2 (the downsampling convs): parity-split patch columns, five staging units per thread; odd sizes, ragged tiles, 2 M tiles
