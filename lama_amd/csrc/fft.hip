@@ -1782,6 +1782,7 @@ int mr_threads(int h, int w, size_t* lds) {
     return 0;
 }
 bool mr_fill(MrParams& q, const FftParams& p, int nt) {
+    memset(&q, 0, sizeof(q));
     q.f = p;
     q.rsw = p.w | 1;
     q.nrp = mr_plan(p.w, q.rrad);

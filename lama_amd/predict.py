@@ -98,8 +98,8 @@ def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
         raise L.LamaError(f"device={cfg['device']}: lama_amd runs on an MI355X only (there is no CPU path)")
     if cfg.get('dataset.kind', 'default') != 'default':
         raise NotImplementedError(f"dataset.kind={cfg['dataset.kind']} (only the default InpaintingDataset of bin/predict.py)")
-    if cfg.get('out_key', 'inpainted') != 'inpainted':
-        raise NotImplementedError('out_key other than inpainted')
+    if cfg.get('out_key', 'inpainted') not in ('inpainted', 'predicted_image'):
+        raise SystemExit(f"out_key={cfg['out_key']!r}: the predict_only forward (trainers/default.py:56-71) produces 'inpainted' and 'predicted_image'")
     return cfg
 
 
@@ -231,8 +231,11 @@ class HostFedStep:
     runs synchronously, unpinned."""
 
     def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'auto',
-                 u8_input: bool = True, tune: bool = True):
+                 u8_input: bool = True, tune: bool = True, out_key: str = 'inpainted'):
         self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
+        if out_key not in ('inpainted', 'predicted_image'):                        # bin/predict.py:86: batch[predict_config.out_key]
+            raise L.LamaError(f"out_key {out_key!r}: 'inpainted' or 'predicted_image'")
+        self.out_key = out_key
         self.device = torch.device(device)
         self.on_gpu = self.device.type == 'cuda'
         self.drain, self.binarize = drain, binarize
@@ -310,7 +313,7 @@ class HostFedStep:
         lib = self.model.generator._exec.lib
         if self.u8_input:                                                                          # bin/predict.py:82-92 in two elementwise launches + the generator
             with torch.no_grad():
-                self.model.forward_u8(self.d_img[p], self.d_mask[p], self.d_sizes[p], self.u8[p], binarize=self.binarize)
+                self.model.forward_u8(self.d_img[p], self.d_mask[p], self.d_sizes[p], self.u8[p], binarize=self.binarize, out_key=self.out_key)
             return
         mask = self.d_mask[p]
         batch = dict(image=self.d_img[p], mask=(mask > 0) * 1 if self.binarize else mask)          # bin/predict.py:84
@@ -318,7 +321,7 @@ class HostFedStep:
         self.model.keep_predicted_image = False
         try:
             with torch.no_grad():
-                out = self.model(batch)['inpainted']                                             # bin/predict.py:85
+                out = self.model(batch)[self.out_key]                                            # bin/predict.py:85-86
         finally:
             self.model.keep_predicted_image = keep
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.on_gpu else 0
@@ -472,7 +475,7 @@ class HostFedStep:
 
 def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[str, str]], indir: str, outdir: str, *,
             pad_mod: int = 8, batch_size: int = 8, out_ext: str = '.png', device='cuda', rank: int = 0, world: int = 1,
-            dist=None, io_threads: int = 8) -> int:
+            dist=None, io_threads: int = 8, out_key: str = 'inpainted') -> int:
     """Run every (mask, image) pair through ``model`` and write the results (rank 0).  Returns the number of images written.
 
     Host pipeline: the PNGs of round r + 1 are decoded / padded on the thread pool while round r computes, results are
@@ -486,7 +489,7 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
         for _attempt in range(2):
             try:
                 return _predict_once(model, items, indir, outdir, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext, device=device,
-                                     rank=rank, world=world, dist=dist, io_threads=io_threads)
+                                     rank=rank, world=world, dist=dist, io_threads=io_threads, out_key=out_key)
             except _RangeRestart:
                 continue                     # the generator switched to the 3-term bf16 split (every rank alike): all images again
         raise L.LamaError('range restart did not converge')
@@ -494,7 +497,7 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
         gen.defer_range_check = keep
 
 
-def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, device, rank, world, dist, io_threads) -> int:
+def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, device, rank, world, dist, io_threads, out_key='inpainted') -> int:
     from PIL import Image
     shapes, sizes = [], []
     for _, im_path in items:                 # padded shape from the IMAGE's PNG header only: every rank builds the same plan
@@ -507,12 +510,12 @@ def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, 
     pool = ThreadPoolExecutor(io_threads)
     try:
         return _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext,
-                               device=device, rank=rank, world=world, dist=dist)
+                               device=device, rank=rank, world=world, dist=dist, out_key=out_key)
     finally:
         pool.shutdown()                      # on every exit path (a raise out of a bucket included): no worker thread outlives the call
 
 
-def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist) -> int:
+def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist, out_key='inpainted') -> int:
     """The rounds of one attempt.  Per bucket (padded shape) a ``HostFedStep``: round k computes from device input set k & 1 while the SAME graph
     launch uploads round k + 1's decoded images into the other set and (one rank) downloads round k - 1's u8 results; the host fills the
     pinned set of round k + 1 and queues round k - 2's PNG writes while round k runs.  Several ranks: the results go through the one
@@ -549,7 +552,7 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         while r1 < len(rounds) and rounds[r1]['shape'] == (Hp, Wp):
             r1 += 1
         K = r1 - r0
-        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS))
+        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS), out_key=out_key)
         gathered = h_out = None
         if world > 1 and rank == 0:
             gathered = [torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device) for _ in range(2)]
@@ -711,7 +714,7 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     import time
     t0 = time.perf_counter()
     n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
-                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist, io_threads=int(cfg['io_threads']))
+                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist, io_threads=int(cfg['io_threads']), out_key=cfg['out_key'])
     dt = time.perf_counter() - t0
     if rank == 0:
         # (the loop's own wall time: plan build + graph capture of every shape bucket, PNG decode, upload, compute, download, PNG encode + write)

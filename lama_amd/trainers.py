@@ -85,12 +85,17 @@ class DefaultInpaintingTrainingModule(nn.Module):
         return batch
 
 
-    def forward_u8(self, image_hwc: torch.Tensor, mask: torch.Tensor, sizes, out_u8: torch.Tensor, binarize: bool = True) -> torch.Tensor:
+    def forward_u8(self, image_hwc: torch.Tensor, mask: torch.Tensor, sizes, out_u8: torch.Tensor, binarize: bool = True,
+                   out_key: str = 'inpainted') -> torch.Tensor:
         """The predict step of bin/predict.py:82-92 on what is on disk (round 6, ABI v110): ``image_hwc`` u8 [B,Hp,Wp,3] and ``mask`` u8 [B,Hp,Wp]
         hold each image's h x w pixels in the top-left corner of its slot, ``sizes`` int32 [B,2] = (h, w) on the device (None: full slots).  The
         first launch does load_image's / 255, pad_img_to_modulo's symmetric padding and predict.py:84's mask > 0 while it composes the
         generator's input (default.py:59,67-68); the last one blends (default.py:71) and writes predict.py:92's clipped u8 HWC image into
-        ``out_u8`` [B,Hp,Wp,3] (returned).  Bit-identical to ``forward`` on the fp32 tensors the reference's host code builds + quantize_u8_hwc."""
+        ``out_u8`` [B,Hp,Wp,3] (returned).  Bit-identical to ``forward`` on the fp32 tensors the reference's host code builds + quantize_u8_hwc.
+        ``out_key`` = bin/predict.py:86's ``batch[predict_config.out_key]``: 'inpainted' (default.py:71) or 'predicted_image' (default.py:70:
+        the generator's output without the blend; the padding columns are cropped by the caller as predict.py:87-90 does)."""
+        if out_key not in ('inpainted', 'predicted_image'):
+            raise L.LamaError(f"out_key {out_key!r}: the predict_only forward produces 'inpainted' and 'predicted_image' (default.py:70-71)")
         ex = self.generator._exec
         if not ex.injected and not image_hwc.is_cuda:
             raise L.LamaError('lama_amd runs on an MI355X only: input tensor is on ' + str(image_hwc.device) + ' (there is no CPU fallback)')
@@ -113,7 +118,10 @@ class DefaultInpaintingTrainingModule(nn.Module):
                 gen.clone_output = keep
         else:
             pred = gen(masked)
-        ex.lib.blend_quantize_u8(image_hwc, mask, sizes, L.view(pred), out_u8, B, binarize, st)
+        if out_key == 'predicted_image':
+            ex.lib.quantize_u8_hwc(L.view(pred), out_u8, B, H, W, st)              # predict.py:92 on batch['predicted_image']
+        else:
+            ex.lib.blend_quantize_u8(image_hwc, mask, sizes, L.view(pred), out_u8, B, binarize, st)
         return out_u8
 
 

@@ -611,3 +611,37 @@ def test_host_fed_step_u8_input_equals_the_host_conversion():
     got[steps - 1] = torch.from_numpy(hs.result((steps - 1) & 1).copy())
     for k in range(steps):
         assert torch.equal(got[k][0], want[k]), k
+
+
+def test_host_fed_step_out_key_predicted_image():
+    """bin/predict.py:86 reads ``batch[predict_config.out_key]``: 'predicted_image' (default.py:70) is the generator's output WITHOUT the blend
+    of default.py:71.  HostFedStep(out_key=...) against the module's forward + the reference's clip / astype('uint8') on the host."""
+    from lama_amd.predict import HostFedStep, parse_overrides
+    cfg = O.small_config(ngf=8, n_blocks=1)
+    sd = {'generator.' + k: v for k, v in O.make_synthetic_state_dict(cfg, seed=12, calib_hw=32).items()}
+    model = trainers.DefaultInpaintingTrainingModule(dict(generator=dict(kind='ffc_resnet', **cfg)))
+    model.load_state_dict(sd, strict=True)
+    model.freeze()
+    model.generator.set_exec(F._Exec(emu_lib()))
+    n, H, W = 1, 32, 40
+    g = torch.Generator().manual_seed(6)
+    image = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8).numpy()
+    mask = (torch.randint(0, 2, (H, W), generator=g) * 255).to(torch.uint8).numpy()
+    batch = model(dict(image=torch.from_numpy(np.transpose(image, (2, 0, 1)).astype('float32') / 255)[None],
+                       mask=(torch.from_numpy(mask[None, None].astype('float32') / 255) > 0) * 1))
+    for key in ('predicted_image', 'inpainted'):
+        want = np.clip(batch[key][0].permute(1, 2, 0).numpy() * 255, 0, 255).astype('uint8')     # predict.py:86,92
+        hs = HostFedStep(model, n, H, W, 'cpu', drain=True, out_key=key)
+        hs.put(0, 0, image, mask)
+        hs.prime(0)
+        hs.launch(0)
+        hs.flush(0)
+        assert np.array_equal(hs.result(0)[0], want), key
+    assert not np.array_equal(np.clip(batch['predicted_image'][0].permute(1, 2, 0).numpy() * 255, 0, 255).astype('uint8'),
+                              np.clip(batch['inpainted'][0].permute(1, 2, 0).numpy() * 255, 0, 255).astype('uint8'))
+    with pytest.raises(F.LamaError):
+        HostFedStep(model, n, H, W, 'cpu', out_key='mask_for_losses')
+    base = ['model.path=/m', 'indir=/i', 'outdir=/o']
+    assert parse_overrides(base + ['out_key=predicted_image'])['out_key'] == 'predicted_image'
+    with pytest.raises(SystemExit):
+        parse_overrides(base + ['out_key=nonsense'])

@@ -201,6 +201,7 @@ FFT_SIZES = [(16, 16), (32, 32), (64, 64), (32, 64), (64, 16), (128, 32), (128, 
              (45, 60), (21, 94), (27, 25),                                    # ... 9x5 / 4x3x5, 3x7 / 2x47 (thread-per-output pass of a prime), 3x3x3 / 5x5
              (9, 14), (35, 30), (22, 26), (1, 16), (3, 2), (49, 56), (67, 40),  # ... 7x2, 5x7 / 2x3x5, primes 11 / 13, degenerate planes, 7x7 / 8x7, a prime height
              (90, 160),                                                       # ... the bottleneck plane of a 720 x 1280 frame (512 threads)
+             (53, 24), (20, 59), (61, 67), (106, 12), (9, 118),               # ... large prime factors (the 2 x 2-blocked pair-symmetric first pass, mr_pass_prime1): prime heights / widths, both, 2 x 53, 2 x 59
              (256, 32), (16, 512), (256, 256)]                                # two-pass LDS path
 
 
@@ -231,7 +232,7 @@ def test_rfft2_irfft2_emulated(hw):
     assert torch.allclose(y2, ref2 - resid, atol=tol, rtol=1e-4)
 
 
-@pytest.mark.parametrize('hw', [(45, 60), (21, 94), (27, 25), (9, 14), (67, 40), (16, 24)], ids=lambda s: f'{s[0]}x{s[1]}')
+@pytest.mark.parametrize('hw', [(45, 60), (21, 94), (27, 25), (9, 14), (67, 40), (16, 24), (53, 24), (20, 59), (61, 67)], ids=lambda s: f'{s[0]}x{s[1]}')
 def test_rfft2_irfft2_two_launch_mixed_radix_emulated(hw, monkeypatch):
     """Round 6: the two-launch form of the mixed-radix passes (mr2_* kernels: planes that do not fit one workgroup's LDS and are not powers of
     two), forced here on small planes (LAMA_FFT_MR=2, profiling build)."""
