@@ -334,8 +334,8 @@ def photo_leg(model, device, lib, steps=8):
         model.load_state_dict(keep, strict=True)
     except Exception as e:      # noqa: BLE001
         out['accuracy_error'] = repr(e)[:300]
-    out['note'] = ('round 6: mixed-radix plane-in-LDS rfft2 / irfft2 for any plane (fft_mr_dev.inc), 128-pixel conv tiles shaped by rounds; the local conv of '
-                   'these planes is the direct kernel (the Winograd launch takes W in {32, 64, 128, 256} only).  1 x 1000 x 1504 is 184 tiles of 128 pixels on 256 CUs: '
+    out['note'] = ('round 6: mixed-radix plane-in-LDS rfft2 / irfft2 for any plane (fft_mr_dev.inc), 128-pixel conv tiles shaped by rounds; the local conv is the '
+                   'Winograd form where lama_winograd_preferred says so (any plane size since ABI v110), the direct kernel otherwise.  1 x 1000 x 1504 is 184 tiles of 128 pixels on 256 CUs: '
                    'every launch runs on three quarters of the chip -- its per-pixel ratio is utilisation, not a slow path')
     torch.cuda.empty_cache()
     return out

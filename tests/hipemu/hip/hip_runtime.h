@@ -349,6 +349,8 @@ static inline float hipemu_f16_residual(unsigned packed, float x, int hi) {
 
 // math helpers that exist in HIP device code
 static inline void sincospi(double x, double* s, double* c) { *s = sin(M_PI * x); *c = cos(M_PI * x); }
+static inline int __mul24(int a, int b) { return a * b; }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline void sincospif(float x, float* s, float* c) { *s = (float)sin(M_PI * (double)x); *c = (float)cos(M_PI * (double)x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }

@@ -529,7 +529,7 @@ def test_split_batch_plan_is_bit_identical(small):
     each part has its own buffers, reads its slice of the input, writes its slice of the output and tags its launches as siblings
     (LAMA_CONV_SIBLINGS_*, v109) -- same bits as the one-part plan; the auto rule never splits on a CPU device."""
     cfg, sd, gen = small
-    batch = O.make_synthetic_batch(4, 32, 48, seed=21)
+    batch = O.make_synthetic_batch(4, 24, 32, seed=21)         # (sized for the CPU suite: eight emulated forwards of four images)
     x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
     seen = []
     real = gen._exec.lib.conv2d
@@ -550,11 +550,14 @@ def test_split_batch_plan_is_bit_identical(small):
             yn = gen(x).clone()
             plan = next(iter(gen._plans.values()))
             assert plan['nsplit'] == n and len(plan['parts']) == n and len(gen._plans) == 1
-            assert torch.equal(yn, y1) and torch.equal(gen(x), y1), n
+            assert torch.equal(yn, y1), n
             assert seen and all(v == n.bit_length() - 1 for v in seen) and gen._exec.siblings_log2 == 0
-            buf = gen.input_buffer(x.shape, x.device)
-            buf.copy_(x)
-            assert torch.equal(gen(buf), y1)
+            if n == 2:
+                assert torch.equal(gen(x), y1)                # the cached plan again
+            else:
+                buf = gen.input_buffer(x.shape, x.device)      # the caller writes the plan's own input buffer
+                buf.copy_(x)
+                assert torch.equal(gen(buf), y1)
         gen.split_batch = 3
         with pytest.raises(F.LamaError):
             gen(x)

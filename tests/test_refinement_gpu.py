@@ -262,6 +262,41 @@ def test_rear_gradients_18_blocks_strict(biglama_module, fwd_prec, bwd_prec, bar
     assert rel < bar and mx < 5 * bar, (rel, mx)
 
 
+def test_rear_gradients_strict_on_256x256_planes(big2):
+    """the strict fixed-mask gradient check ran at 256^2 only, so the masked transforms of the reverse pass
+    (lama_rfft2_masked_fwd / lama_irfft2_masked_fwd: the two ReLU derivatives of the spectral branch inside the 256 x 256-plane two-pass FFT
+    kernels, v108) were pinned by the trajectory goldens and a kernel-level test only.  Here: d <gw, pred> / d (z1, z2) through two
+    FFCResnetBlocks at big-lama's channel counts, the three ConvTranspose2d adjoints and the head at 2048 x 2048 -- bottleneck planes of
+    256 x 256, BASELINE configs[4]'s top scale -- against torch autograd through the oracle with the ReLU masks of the HIP tape
+    (tests/masked_oracle.py): only rounding separates the two.  Exact fp32 both ways; bars as test_rear_gradients_18_blocks_strict."""
+    from tests import masked_oracle as MO
+    cfg, sd = big2
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen.cuda().set_precision(L.PREC_F32)
+    fri = R.first_resblock_index(cfg)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    batch = O.make_synthetic_batch(1, 2048, 2048, seed=9)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        z1, z2 = O.run_layers(x, sd, cfg, 0, fri)
+    assert tuple(z1.shape[-2:]) == (256, 256)
+    rear = RearPass(gen, fri, bwd_precision=L.PREC_F32)
+    pred = rear.forward(torch.cat([z1, z2], 1).contiguous().to(DEV))
+    gw = torch.randn(pred.shape, generator=torch.Generator().manual_seed(7)) / pred.numel()
+    g = rear.backward(gw.contiguous().to(DEV)).cpu()
+    assert rear._plan['sh'].get('fft_mask', True) is True              # the masked-transform entries took the launch (not the act_bwd fallback)
+    masks = MO.tape_masks(rear)
+    assert len(masks) == 2 * 2 * 4 + 3
+    pred_ref, gref = MO.rear_gradient(z1, z2, sd, cfg, fri, gw, masks)
+    rel = float((g - gref).norm() / gref.norm())
+    mx = float((g - gref).abs().max() / gref.abs().max())
+    perr = float((pred.cpu() - pred_ref).abs().max())
+    print(f'2 blocks, 2048^2 (256 x 256 planes, masked FFT entries): gradient rel L2 {rel:.2e} (max / gmax {mx:.2e}), pred max-abs {perr:.2e}', flush=True)
+    assert perr < 1e-4, perr
+    assert rel < 5e-5 and mx < 2.5e-4, (rel, mx)
+
+
 @pytest.mark.parametrize('case', [(1, 64, 64), (1, 30, 50), (3, 128, 256)])
 def test_reflect_pad_adjoint_fused_matches_separate_launches(case):
     """lama_reflect_pad_bwd_fused (v108) against fold + add + act_bwd as separate launches, on channel views of the 512-channel state
