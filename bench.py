@@ -382,10 +382,17 @@ def predict_cli_leg(model, n_images=512, res=512, io_threads=(8, 16, 32, 64)):
         dec = (time.process_time() - t0) / 32
         arr = np.asarray(Image.open(os.path.join(indir, 'im0000.png')).convert('RGB'))
         t0 = time.process_time()
+        from lama_amd.predict import _write_png
         for i in range(32):
-            Image.fromarray(arr).save(os.path.join(root, 'enc.png'), compress_level=1)
+            _write_png(os.path.join(root, 'enc.png'), arr)
         enc = (time.process_time() - t0) / 32
-        out['host_cpu_s_per_image'] = dict(png_decode_image_and_mask=round(dec, 5), png_encode_result=round(enc, 5), note='single thread, PIL; zlib level 1 on write = cv2.imwrite\'s PNG default (what bin/predict.py:94 uses); uniform-noise images: incompressible, the expensive end of real content')
+        t0 = time.process_time()
+        for i in range(8):
+            Image.fromarray(arr).save(os.path.join(root, 'enc_pil.png'), compress_level=1)
+        enc_pil = (time.process_time() - t0) / 8
+        out['host_cpu_s_per_image'] = dict(png_decode_image_and_mask=round(dec, 5), png_encode_result=round(enc, 5), png_encode_result_pil_level1=round(enc_pil, 5),
+                                           note='single thread; decode: PIL; encode: lama_amd.predict.encode_png -- filter Sub + zlib level 1 + Z_RLE = cv2.imwrite\'s PNG defaults (what bin/predict.py:94 uses), '
+                                                'beside PIL\'s encoder at level 1 (what the CLI used until round 6, third session); uniform-noise images: incompressible, the expensive end of real content')
         runs = {}
         for T in io_threads:
             od = os.path.join(root, f'out{T}')

@@ -187,12 +187,43 @@ class _RangeRestart(Exception):
     """A forward of this run left the fp16 split's range: the generator is on the bf16 split now, the run starts over."""
 
 
+def encode_png(rgb: np.ndarray) -> bytes:
+    """An 8-bit RGB (or gray) image as PNG bytes with the parameters cv2.imwrite uses by default (bin/predict.py:94: IMWRITE_PNG_COMPRESSION
+    unset -> libpng filter SUB, zlib level 1, strategy Z_RLE): the Sub filter as one numpy subtraction, one zlib stream, one IDAT chunk.
+    Same decoded pixels as any PNG writer; 7.4 ms per 512 x 512 image where PIL's encoder (adaptive filter choice per row, default strategy)
+    takes 56 ms at the same level -- the CLI was encode-bound on the host at 0.47 of the GPU rate (bench.py predict_cli_leg, round 6)."""
+    import struct
+    import zlib
+    a = np.ascontiguousarray(rgb)
+    if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] not in (1, 3)):
+        raise L.LamaError(f'encode_png: uint8 [H,W] / [H,W,3] image, got {a.dtype} {a.shape}')
+    h, w = a.shape[:2]
+    c = 1 if a.ndim == 2 else a.shape[2]
+    flat = a.reshape(h, w * c)
+    raw = np.empty((h, 1 + w * c), np.uint8)
+    raw[:, 0] = 1                                              # filter type Sub: byte - byte of the pixel to the left (mod 256)
+    raw[:, 1:1 + c] = flat[:, :c]
+    raw[:, 1 + c:] = flat[:, c:] - flat[:, :-c]
+    co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_RLE)
+    data = co.compress(raw.tobytes()) + co.flush()
+
+    def chunk(tag: bytes, body: bytes) -> bytes:
+        return struct.pack('>I', len(body)) + tag + body + struct.pack('>I', zlib.crc32(tag + body) & 0xffffffff)
+
+    ihdr = struct.pack('>IIBBBBB', w, h, 8, 2 if c == 3 else 0, 0, 0, 0)
+    return b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', ihdr) + chunk(b'IDAT', data) + chunk(b'IEND', b'')
+
+
 def _write_png(path: str, rgb: np.ndarray):
-    from PIL import Image
+    """bin/predict.py:93-94 (the reference converts RGB -> BGR only because cv2.imwrite expects BGR).  ``.png``: encode_png; any other
+    extension goes through PIL, which picks the format from it as cv2.imwrite does."""
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    # the reference converts RGB->BGR only because cv2.imwrite expects BGR; zlib level 1 is cv2.imwrite's PNG default (IMWRITE_PNG_COMPRESSION = 1), PIL's
-    # own default (6) costs 3-5x the CPU time per image for the same pixels
-    Image.fromarray(rgb).save(path, compress_level=1)
+    if path.lower().endswith('.png'):
+        with open(path, 'wb') as f:
+            f.write(encode_png(rgb))
+        return
+    from PIL import Image
+    Image.fromarray(rgb).save(path)
 
 
 # ----------------------------------------------------------------------------------------------------------------

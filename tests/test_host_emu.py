@@ -648,3 +648,34 @@ def test_host_fed_step_out_key_predicted_image():
     assert parse_overrides(base + ['out_key=predicted_image'])['out_key'] == 'predicted_image'
     with pytest.raises(SystemExit):
         parse_overrides(base + ['out_key=nonsense'])
+
+
+def test_encode_png_round_trips_and_matches_cv2_defaults():
+    """lama_amd.predict.encode_png (what the CLI writes for out_ext=.png, bin/predict.py:93-94): any PNG reader returns the same pixels; the stream
+    is ONE IDAT with filter type Sub on every row and a zlib header of level 1 -- cv2.imwrite's defaults (filter SUB, Z_BEST_SPEED, Z_RLE)."""
+    import io
+    import struct
+    import zlib
+    from PIL import Image
+    from lama_amd.predict import encode_png, _write_png
+    g = np.random.default_rng(3)
+    for shape in ((37, 50, 3), (1, 1, 3), (8, 300, 3), (16, 16)):
+        a = g.integers(0, 256, shape, dtype=np.uint8)
+        if len(shape) == 3:
+            a[: shape[0] // 2] = a[0, 0]                       # flat rows: the run-length strategy must reproduce them too
+        png = encode_png(a)
+        back = np.asarray(Image.open(io.BytesIO(png)))
+        assert back.shape == a.shape and np.array_equal(back, a), shape
+        assert png[:8] == b'\x89PNG\r\n\x1a\n' and png[12:16] == b'IHDR' and png.count(b'IDAT') == 1
+        n = struct.unpack('>I', png[33:37])[0]
+        assert png[37:41] == b'IDAT'
+        raw = zlib.decompress(png[41:41 + n])
+        stride = 1 + a.shape[1] * (3 if a.ndim == 3 else 1)
+        assert len(raw) == a.shape[0] * stride and set(raw[::stride]) == {1}      # filter type Sub on every row
+        assert png[41] == 0x78 and png[42] == 0x01                                  # zlib header: deflate, 32 K window, FLEVEL 0 = level 1
+    with pytest.raises(F.LamaError):
+        encode_png(np.zeros((4, 4, 3), np.float32))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        _write_png(os.path.join(d, 'sub', 'x.png'), a if a.ndim == 3 else np.stack([a] * 3, -1))
+        assert os.path.getsize(os.path.join(d, 'sub', 'x.png')) > 0
