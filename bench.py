@@ -413,6 +413,30 @@ def predict_cli_leg(model, n_images=512, res=512, io_threads=(8, 16, 32, 64)):
             best = max(ok.values())
             sat = min(k for k, v in ok.items() if v >= 0.97 * best)
             out['value'], out['unit'], out['saturates_at_io_threads'] = best, 'images/s', sat
+            # the loop time of 512 images is mostly the bucket's set-up (plan build, split-plan timing check, graph capture): the STEADY rate is the slope
+            # between this directory and one three times its size (hard links to the same files), at the thread count that saturated
+            try:
+                big = os.path.join(root, 'in3')
+                os.makedirs(big)
+                for rep in range(3):
+                    for i in range(n_images):
+                        os.link(os.path.join(indir, f'im{i:04d}.png'), os.path.join(big, f'r{rep}im{i:04d}.png'))
+                        os.link(os.path.join(indir, f'im{i:04d}_mask001.png'), os.path.join(big, f'r{rep}im{i:04d}_mask001.png'))
+                od = os.path.join(root, 'out3')
+                r = subprocess.run([sys.executable, '-m', 'lama_amd.predict', f'model.path={mdir}', f'indir={big}', f'outdir={od}', f'io_threads={sat}'],
+                                   cwd=ROOT, capture_output=True, text=True, timeout=900)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith('wrote ')]
+                if r.returncode == 0 and line:
+                    secs3 = float(line[-1].split(' in ')[1].split(' s')[0])
+                    secs1 = runs[str(sat)]['loop_s']
+                    out['steady_state'] = dict(images_per_s=round(2 * n_images / max(secs3 - secs1, 1e-9), 1), loop_s_3x=round(secs3, 3), loop_s_1x=secs1, io_threads=sat,
+                                               bucket_setup_s=round(secs1 - n_images * (secs3 - secs1) / (2 * n_images), 3),
+                                               note=f'slope between {n_images} and {3 * n_images} images: the rate a long directory sees; bucket_setup_s = the fixed part of the loop time')
+                else:
+                    out['steady_state'] = dict(error=(r.stderr or r.stdout)[-300:])
+                shutil.rmtree(od, ignore_errors=True)
+            except Exception as e:      # noqa: BLE001
+                out['steady_state'] = dict(error=repr(e)[:300])
             cores = 830.0 * (dec + enc)
             out['host_cores_for_8_ranks_at_830_images_per_s'] = round(8 * cores, 1)
             out['statement'] = (f'one rank at 830 images/s needs {cores:.1f} host cores of PNG decode + encode ({dec * 1e3:.1f} + {enc * 1e3:.1f} ms per image on this host); '

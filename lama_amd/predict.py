@@ -22,6 +22,7 @@ from __future__ import annotations
 import glob
 import os
 import sys
+import time
 from concurrent.futures import ThreadPoolExecutor
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -42,7 +43,7 @@ DEFAULTS = {'model.checkpoint': 'best.ckpt', 'dataset.img_suffix': '.png', 'data
 # ----------------------------------------------------------------------------------------------------------------
 
 # keys of configs/prediction/default.yaml this driver honours; anything else is rejected instead of silently ignored
-KNOWN_KEYS = set(DEFAULTS) | {'model.path', 'indir', 'outdir', 'device', 'dataset.kind', 'refine',
+KNOWN_KEYS = set(DEFAULTS) | {'model.path', 'indir', 'outdir', 'device', 'dataset.kind', 'refine', 'profile',
                               'refiner.gpu_ids', 'refiner.modulo', 'refiner.n_iters', 'refiner.lr', 'refiner.min_side',
                               'refiner.max_scales', 'refiner.px_budget'}
 REFINER_DEFAULTS = {'refiner.gpu_ids': '0,', 'refiner.modulo': 8, 'refiner.n_iters': 15, 'refiner.lr': 0.002, 'refiner.min_side': 512,
@@ -53,7 +54,7 @@ REFINER_DEFAULTS = {'refiner.gpu_ids': '0,', 'refiner.modulo': 8, 'refiner.n_ite
 # a file name); everything else is a bool / int / float as in the YAML defaults
 STRING_KEYS = {'model.path', 'model.checkpoint', 'indir', 'outdir', 'device', 'dataset.kind', 'dataset.img_suffix', 'out_ext', 'out_key',
                'precision', 'refiner.gpu_ids'}
-BOOL_KEYS = {'refine'}
+BOOL_KEYS = {'refine', 'profile'}
 INT_KEYS = {'dataset.pad_out_to_modulo', 'batch_size', 'io_threads', 'refiner.modulo', 'refiner.n_iters', 'refiner.min_side', 'refiner.max_scales',
             'refiner.px_budget'}
 FLOAT_KEYS = {'refiner.lr'}
@@ -180,6 +181,8 @@ def gather_to_root(dist, gathered: Optional[torch.Tensor], part: torch.Tensor, r
     return dist.gather(part, gather_list=parts, dst=root, async_op=True)
 
 
+PROFILE_SPANS = False                    # profile=true: HostFedStep records timing events around every step's compute
+LOOP_TIMES: Dict[str, float] = {}      # wall seconds of the main thread per phase of the round loop (python -m lama_amd.predict ... profile=true prints them)
 TUNE_MIN_ROUNDS = 4      # buckets with fewer rounds skip the split-plan timing check and graph mode (HostFedStep(tune=False))
 
 
@@ -212,6 +215,39 @@ def encode_png(rgb: np.ndarray) -> bytes:
 
     ihdr = struct.pack('>IIBBBBB', w, h, 8, 2 if c == 3 else 0, 0, 0, 0)
     return b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', ihdr) + chunk(b'IDAT', data) + chunk(b'IEND', b'')
+
+
+class _Latch:
+    """Count-down latch: the round loop waits on it before a pinned result set is overwritten while pool workers still snapshot it."""
+
+    def __init__(self):
+        import threading
+        self._c, self._n = threading.Condition(), 0
+
+    def add(self, n: int = 1):
+        with self._c:
+            self._n += n
+
+    def done(self):
+        with self._c:
+            self._n -= 1
+            if self._n <= 0:
+                self._c.notify_all()
+
+    def wait(self):
+        with self._c:
+            while self._n > 0:
+                self._c.wait()
+
+
+def _snap_and_write(path: str, view: np.ndarray, latch: _Latch, pool):
+    """``fast`` pool job: copy the image out of the pinned result set (then release the latch: the set may be overwritten) and queue its encode +
+    write on ``pool``; returns that future."""
+    try:
+        rgb = view.copy()
+    finally:
+        latch.done()
+    return pool.submit(_write_png, path, rgb)
 
 
 def _write_png(path: str, rgb: np.ndarray):
@@ -309,6 +345,7 @@ class HostFedStep:
         self.h_u8 = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, **pin) for _ in range(2)] if drain else None
         self.u8 = [torch.zeros(self.n, Hp, Wp, 3, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.graphs = [None, None]
+        self.span_events = None       # a list: launch() (mode 'host') appends (start, end) timing events around each step's compute
         self.done = [torch.cuda.Event() for _ in range(2)] if self.on_gpu else None
         self._launched = [False, False]
         self._h2d_issued = [False, False]
@@ -440,7 +477,13 @@ class HostFedStep:
             try:
                 if self._h2d_issued[p]:
                     main.wait_event(self.h2d[p])
+                if self.span_events is not None:       # profile=true: the step's span on the GPU clock
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(main)
                 self._compute(p)
+                if self.span_events is not None:
+                    ev[1].record(main)
+                    self.span_events.append(ev)
             finally:
                 gen.use_graph, gen.defer_range_check = keep[:2]
                 if self.one_part:
@@ -530,29 +573,41 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
 
 def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, device, rank, world, dist, io_threads, out_key='inpainted') -> int:
     from PIL import Image
-    shapes, sizes = [], []
-    for _, im_path in items:                 # padded shape from the IMAGE's PNG header only: every rank builds the same plan
-        with Image.open(im_path) as im:
+
+    def header_size(item):                   # padded shape from the IMAGE's PNG header only: every rank builds the same plan
+        with Image.open(item[1]) as im:
             w, h = im.size
-        sizes.append((h, w))
-        shapes.append((ceil_modulo(h, pad_mod), ceil_modulo(w, pad_mod)) if pad_mod and pad_mod > 1 else (h, w))
-    rounds = plan_rounds(shapes, batch_size, world)
+        return h, w
+
     lib = model.generator._exec.lib
     pool = ThreadPoolExecutor(io_threads)
+    # the copies into / out of the pinned sets are on the round loop's critical path (the next launch waits for them) and take 0.1-0.3 ms each: they
+    # get workers of their own instead of queueing behind milliseconds of PNG work in ``pool``
+    fast = ThreadPoolExecutor(min(4, max(1, io_threads)))
     try:
+        sizes = list(pool.map(header_size, items, chunksize=64))       # (0.15 ms per file on the main thread was a tenth of a long directory's wall time)
+        shapes = [(ceil_modulo(h, pad_mod), ceil_modulo(w, pad_mod)) if pad_mod and pad_mod > 1 else (h, w) for h, w in sizes]
+        rounds = plan_rounds(shapes, batch_size, world)
         return _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext,
-                               device=device, rank=rank, world=world, dist=dist, out_key=out_key)
+                               device=device, rank=rank, world=world, dist=dist, out_key=out_key, fast=fast)
     finally:
+        fast.shutdown()
         pool.shutdown()                      # on every exit path (a raise out of a bucket included): no worker thread outlives the call
 
 
-def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist, out_key='inpainted') -> int:
+def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist, out_key='inpainted', fast=None) -> int:
     """The rounds of one attempt.  Per bucket (padded shape) a ``HostFedStep``: round k computes from device input set k & 1 while the SAME graph
     launch uploads round k + 1's decoded images into the other set and (one rank) downloads round k - 1's u8 results; the host fills the
     pinned set of round k + 1 and queues round k - 2's PNG writes while round k runs.  Several ranks: the results go through the one
     collective -- ``gather_to_root`` of the u8 batch, on a side stream behind the step -- and rank 0 downloads the gathered rounds."""
-    futures, written = [], 0
+    futures, written = [], 0                 # futures of the snapshot jobs; each returns the future of its encode + write
+    fast = fast if fast is not None else pool
     bucket_paths: List[str] = []             # the PNGs queued for the bucket whose range flag has not been read yet
+
+    def drain():
+        for f in futures:
+            f.result().result()
+
     on_gpu = torch.device(device).type == 'cuda'
     side = torch.cuda.Stream(device=device) if on_gpu else None     # gather + D2H of the gathered rounds, beside the next round's compute
 
@@ -562,8 +617,12 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         if r < len(rounds) and r not in loads:
             loads[r] = [pool.submit(load_item_u8, *items[i]) for i in rounds[r]['batches'][rank]]      # decode only: / 255, padding, mask > 0 run on the device
 
-    def write_round(rd, host):
-        """Rank 0: queue the PNG writes of one round from its u8 results on the host (``host`` = [ranks * batch_size, Hp, Wp, 3])."""
+    snapped = [_Latch(), _Latch()]           # per pinned result set: the workers that still copy their image out of it
+
+    def write_round(rd, host, pset):
+        """Rank 0: queue the PNG writes of one round from its u8 results on the host (``host`` = [ranks * batch_size, Hp, Wp, 3] = pinned result
+        set ``pset``).  The workers snapshot their image themselves (the main thread only queues); ``snapped[pset].wait()`` before that set is
+        downloaded into again."""
         nonlocal written
         for r, idxs in enumerate(rd['batches']):
             for j, i in enumerate(idxs):
@@ -571,7 +630,8 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
                 h, w = sizes[i]
                 rel = os.path.splitext(mask_path[len(indir):].lstrip(os.sep))[0] + out_ext      # bin/predict.py:69-72
                 bucket_paths.append(os.path.join(outdir, rel))
-                futures.append(pool.submit(_write_png, bucket_paths[-1], host[r * batch_size + j, :h, :w].copy()))
+                snapped[pset].add()
+                futures.append(fast.submit(_snap_and_write, bucket_paths[-1], host[r * batch_size + j, :h, :w], snapped[pset], pool))
                 written += 1
 
     submit_loads(0)
@@ -583,7 +643,11 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         while r1 < len(rounds) and rounds[r1]['shape'] == (Hp, Wp):
             r1 += 1
         K = r1 - r0
+        t_ = time.perf_counter()
         hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS), out_key=out_key)
+        LOOP_TIMES['bucket_setup'] = LOOP_TIMES.get('bucket_setup', 0.0) + time.perf_counter() - t_
+        if PROFILE_SPANS:
+            hs.span_events = []
         gathered = h_out = None
         if world > 1 and rank == 0:
             gathered = [torch.empty(world * batch_size, Hp, Wp, 3, dtype=torch.uint8, device=device) for _ in range(2)]
@@ -592,15 +656,22 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         collected = [torch.cuda.Event() for _ in range(2)] if (on_gpu and world > 1) else None
 
         def fill(pp, r):
+            t_ = time.perf_counter()
             loaded = [f.result() for f in loads.pop(r)]
-            for j in range(batch_size):                                               # partial (or, for a rank without a batch, empty) round: empty slots
+            LOOP_TIMES['wait_decode'] = LOOP_TIMES.get('wait_decode', 0.0) + time.perf_counter() - t_
+            t_ = time.perf_counter()
+
+            def put(j):                                                               # partial (or, for a rank without a batch, empty) round: empty slots
                 if j < len(loaded):
                     hs.put(pp, j, loaded[j][0], loaded[j][1])
                 else:
                     hs.put(pp, j, None, None)
+            list(fast.map(put, range(batch_size)))                                    # the copies into the pinned set, side by side (distinct slots)
+            LOOP_TIMES['fill_pinned'] = LOOP_TIMES.get('fill_pinned', 0.0) + time.perf_counter() - t_
 
         def collect(pp):
             """Several ranks: the round that launch(pp) just computed goes through the gather (side stream, behind the step); rank 0 downloads it."""
+            snapped[pp].wait()                    # h_out[pp] is downloaded into again: round k - 2's images have been copied out of it
             if on_gpu:
                 with torch.cuda.stream(side):
                     side.wait_event(hs.done[pp])
@@ -617,7 +688,9 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
 
         fill(0, r0)
         submit_loads(r0 + 2)
+        t_ = time.perf_counter()
         hs.prime(0)
+        LOOP_TIMES['bucket_setup'] += time.perf_counter() - t_
         for k in range(K):
             pp = k & 1
             if k + 1 < K:
@@ -626,32 +699,45 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
             submit_loads(r0 + k + 3)
             if on_gpu and works[pp] is not None:
                 torch.cuda.current_stream(hs.device).wait_event(collected[pp])        # step k - 2's gather has read u8[pp]
+            t_ = time.perf_counter()
+            snapped[1 - pp].wait()                # (one rank) this launch downloads into result set 1 - pp: round k - 3's images have been copied out of it
             hs.launch(pp)
+            LOOP_TIMES['launch'] = LOOP_TIMES.get('launch', 0.0) + time.perf_counter() - t_
             if world > 1:
                 collect(pp)
                 if k >= 1:                        # round k - 1: gathered and downloaded while step k runs
                     if on_gpu:
                         collected[1 - pp].synchronize()
                     if rank == 0:
-                        write_round(rounds[r0 + k - 1], h_out[1 - pp].numpy())
+                        write_round(rounds[r0 + k - 1], h_out[1 - pp].numpy(), 1 - pp)
             elif k >= 1:
+                t_ = time.perf_counter()
                 hs.wait(1 - pp)                   # step k - 1 is complete: it downloaded round k - 2 and read the host set filled above
+                LOOP_TIMES['wait_step'] = LOOP_TIMES.get('wait_step', 0.0) + time.perf_counter() - t_
                 if k >= 2:
-                    write_round(rounds[r0 + k - 2], hs.result(pp))
+                    t_ = time.perf_counter()
+                    write_round(rounds[r0 + k - 2], hs.result(pp), pp)
+                    LOOP_TIMES['queue_writes'] = LOOP_TIMES.get('queue_writes', 0.0) + time.perf_counter() - t_
         pl = (K - 1) & 1
         if world > 1:
             if on_gpu:
                 collected[pl].synchronize()
             if rank == 0:
-                write_round(rounds[r1 - 1], h_out[pl].numpy())
+                write_round(rounds[r1 - 1], h_out[pl].numpy(), pl)
         else:
             hs.wait(pl)
             if K >= 2:
-                write_round(rounds[r1 - 2], hs.result(1 - pl))
+                write_round(rounds[r1 - 2], hs.result(1 - pl), 1 - pl)
+            snapped[pl].wait()
             hs.flush(pl)
-            write_round(rounds[r1 - 1], hs.result(pl))
+            write_round(rounds[r1 - 1], hs.result(pl), pl)
         if on_gpu:
             torch.cuda.current_stream(hs.device).synchronize()                      # every rank: the graphs / buffers below are idle now
+            if hs.span_events:
+                ev = hs.span_events
+                LOOP_TIMES['gpu_step_spans'] = LOOP_TIMES.get('gpu_step_spans', 0.0) + sum(a.elapsed_time(b) for a, b in ev) * 1e-3
+                LOOP_TIMES['gpu_first_start_to_last_end'] = LOOP_TIMES.get('gpu_first_start_to_last_end', 0.0) + ev[0][0].elapsed_time(ev[-1][1]) * 1e-3
+                LOOP_TIMES['steps'] = LOOP_TIMES.get('steps', 0.0) + len(ev)
 
         # the bucket's ONE read-back of the fp16 split's range flag (the forwards above did not synchronise); all ranks decide alike
         def red(bad, _dev=hs.device):
@@ -664,22 +750,19 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
         try:
             in_range = model.generator.check_range(hs.device, reduce=red if world > 1 else None)
         except L.LamaRangeError:
-            for f in futures:
-                f.result()
+            drain()
             for pth in bucket_paths:
                 if os.path.exists(pth):
                     os.remove(pth)
             raise
         if not in_range:
-            for f in futures:
-                f.result()
+            drain()
             raise _RangeRestart()
         bucket_paths.clear()
         model.generator.drop_plan((batch_size, 4, Hp, Wp), hs.device)               # bucket done: free its buffers / graphs
         del hs, gathered, h_out
         r0 = r1
-    for f in futures:
-        f.result()
+    drain()
     return written
 
 
@@ -742,7 +825,9 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
             dist.destroy_process_group()
         print(f'rank {rank}: wrote {n} refined images to {cfg["outdir"]}')
         return 0
-    import time
+    if cfg.get('profile', False):
+        global PROFILE_SPANS
+        PROFILE_SPANS = True
     t0 = time.perf_counter()
     n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
                 out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist, io_threads=int(cfg['io_threads']), out_key=cfg['out_key'])
@@ -750,6 +835,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
     if rank == 0:
         # (the loop's own wall time: plan build + graph capture of every shape bucket, PNG decode, upload, compute, download, PNG encode + write)
         print(f'wrote {n} images to {cfg["outdir"]} in {dt:.3f} s ({n / max(dt, 1e-9):.1f} images/s, {world} rank(s), io_threads={int(cfg["io_threads"])})')
+        if cfg.get('profile', False):
+            print('main-thread seconds per phase of the round loop: ' + ', '.join(f'{k} {v:.3f}' for k, v in sorted(LOOP_TIMES.items())))
     if world > 1:
         dist.destroy_process_group()
     return 0
