@@ -163,7 +163,9 @@ def plan_rounds(shapes: Sequence[Tuple[int, int]], batch_size: int, world: int) 
     for i, s in enumerate(shapes):
         buckets.setdefault(tuple(s), []).append(i)
     rounds = []
-    for shape in sorted(buckets):
+    # largest padded shape first: the activation / pinned buffers of every later bucket then fit blocks the caching allocators already hold
+    # (ascending order paid a round of hipMalloc / hipHostMalloc calls per new shape: ~30 ms each in a directory of differently sized photos)
+    for shape in sorted(buckets, key=lambda hw: (-hw[0] * hw[1], hw)):
         idx = buckets[shape]
         batches = [idx[i:i + batch_size] for i in range(0, len(idx), batch_size)]
         for r0 in range(0, len(batches), world):
@@ -311,8 +313,10 @@ class HostFedStep:
         self.one_part = False
         if mode == 'auto' and not tune:
             # a bucket of a few rounds: tune_split's two plans, two captures and 20 replays -- and graph mode's own captures -- cost more
-            # than they can return; the one-part plan replayed beside the copy streams needs one warm-up and one capture
-            mode, self.one_part = 'replay', True
+            # than they can return.  Round 6, third session: not even ONE capture -- the one-part plan as plain launches beside the copy streams
+            # (a warm-up + capture + instantiate is 10-40 ms per new shape, tools/newshape_probe.py; the ~270 launches of a step cost the host 3 ms,
+            # less than the step takes on the GPU at any size)
+            mode, self.one_part = 'streams', True
         if mode == 'auto':      # by measurement (table above): copy nodes overlap only in a graph that has parallel kernel branches already
             gen = model.generator
             split = 1
