@@ -185,7 +185,8 @@ def gather_to_root(dist, gathered: Optional[torch.Tensor], part: torch.Tensor, r
 
 PROFILE_SPANS = False                    # profile=true: HostFedStep records timing events around every step's compute
 LOOP_TIMES: Dict[str, float] = {}      # wall seconds of the main thread per phase of the round loop (python -m lama_amd.predict ... profile=true prints them)
-TUNE_MIN_ROUNDS = 4      # buckets with fewer rounds skip the split-plan timing check and graph mode (HostFedStep(tune=False))
+TUNE_MIN_ROUNDS = 1024    # buckets with fewer rounds skip the split-plan timing check: ~0.35 s for at most 5 % of the bucket's time (HostFedStep(tune=False))
+CAPTURE_MIN_ROUNDS = 32   # ... and with fewer than this also the graph capture: ~30 ms for ~8 % of a round's 10 ms (HostFedStep(capture=False): plain launches)
 
 
 class _RangeRestart(Exception):
@@ -300,7 +301,7 @@ class HostFedStep:
     runs synchronously, unpinned."""
 
     def __init__(self, model, batch_size: int, Hp: int, Wp: int, device, *, drain: bool = True, binarize: bool = True, mode: str = 'auto',
-                 u8_input: bool = True, tune: bool = True, out_key: str = 'inpainted'):
+                 u8_input: bool = True, tune: bool = True, out_key: str = 'inpainted', capture: bool = True):
         self.model, self.n, self.Hp, self.Wp = model, int(batch_size), int(Hp), int(Wp)
         if out_key not in ('inpainted', 'predicted_image'):                        # bin/predict.py:86: batch[predict_config.out_key]
             raise L.LamaError(f"out_key {out_key!r}: 'inpainted' or 'predicted_image'")
@@ -311,12 +312,15 @@ class HostFedStep:
         if mode not in ('auto', 'replay', 'streams', 'graph', 'host'):
             raise L.LamaError(f'HostFedStep mode {mode!r}: auto, replay, streams, graph or host')
         self.one_part = False
-        if mode == 'auto' and not tune:
-            # a bucket of a few rounds: tune_split's two plans, two captures and 20 replays -- and graph mode's own captures -- cost more
-            # than they can return.  Round 6, third session: not even ONE capture -- the one-part plan as plain launches beside the copy streams
-            # (a warm-up + capture + instantiate is 10-40 ms per new shape, tools/newshape_probe.py; the ~270 launches of a step cost the host 3 ms,
-            # less than the step takes on the GPU at any size)
+        if mode == 'auto' and not capture:
+            # a bucket of a few rounds (round 6, third session): not even ONE graph capture -- the one-part plan as plain launches beside
+            # the copy streams (a warm-up + capture + instantiate is 10-40 ms per new shape, tools/newshape_probe.py; the ~270 launches of a step
+            # cost the host 3 ms, less than the step takes on the GPU at any size)
             mode, self.one_part = 'streams', True
+        elif mode == 'auto' and not tune:
+            # a bucket of tens to hundreds of rounds: the one-part plan, captured once, in the host-synchronised form -- tune_split's two plans, two
+            # captures and 18 replays (~0.35 s) buy at most 5 % of the bucket's time
+            mode, self.one_part = ('host' if self.on_gpu else 'replay'), True
         if mode == 'auto':      # by measurement (table above): copy nodes overlap only in a graph that has parallel kernel branches already
             gen = model.generator
             split = 1
@@ -648,7 +652,7 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
             r1 += 1
         K = r1 - r0
         t_ = time.perf_counter()
-        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS), out_key=out_key)
+        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS), capture=(K >= CAPTURE_MIN_ROUNDS), out_key=out_key)
         LOOP_TIMES['bucket_setup'] = LOOP_TIMES.get('bucket_setup', 0.0) + time.perf_counter() - t_
         if PROFILE_SPANS:
             hs.span_events = []

@@ -43,11 +43,11 @@ def main():
                 f.write(encode_png(base[oy:oy + 512, ox:ox + 512]))
             with open(os.path.join(indir, f'im{i:05d}_mask001.png'), 'wb') as f:
                 f.write(mpng)
-        for T in threads:
+        for T, X in [(t, x) for t in threads for x in ([[]] if not extra else [[], extra])]:
             od = os.path.join(root, f'out{T}')
-            r = subprocess.run([sys.executable, '-m', 'lama_amd.predict', f'model.path={mdir}', f'indir={indir}', f'outdir={od}', f'io_threads={T}', 'profile=true'] + extra,
+            r = subprocess.run([sys.executable, '-m', 'lama_amd.predict', f'model.path={mdir}', f'indir={indir}', f'outdir={od}', f'io_threads={T}', 'profile=true'] + X,
                                cwd=ROOT, capture_output=True, text=True, timeout=900)
-            print(f'== io_threads={T}', flush=True)
+            print(f'== io_threads={T} {" ".join(X)}', flush=True)
             print('\n'.join(ln for ln in (r.stdout + r.stderr).splitlines() if ln.startswith(('wrote', 'main-thread')) or 'Error' in ln), flush=True)
             shutil.rmtree(od, ignore_errors=True)
     finally:
