@@ -20,7 +20,7 @@ The JSON line also carries
                    `peak_sustained` is what THIS box sustains on random operands with nothing but MFMAs in flight (measured
                    live through the profiling build's lama_debug_mfma_peak: the part is power limited) and
                    `frac_of_sustained` prices the kernel against that.  `traffic` comes from the committed PMC passes
-                   (profiles/r05_pmc.json: in-pipeline counter passes of this round's launch sequence; a live bench run cannot host the profiler).
+                   (profiles/r06_pmc.json: in-pipeline counter passes of this round's launch sequence; a live bench run cannot host the profiler).
   roofline_ffc  -- the unit BASELINE.json names: FourierUnit forward (rfft2 -> spectral 1x1+BN+ReLU ->
                    irfft2 + residual), algorithmic bytes / time against the 8 TB/s HBM peak.
   cpu_baseline  -- the oracle (CPU restatement of the reference, same torch-CPU primitives) timed on
@@ -890,7 +890,7 @@ def main():
                         measured='HIP events around every launch in 3 eager steps of the ONE-PART plan after the timed region, on the launch stream: the launch '
                                  'over the whole batch alone on the chip (the timed region runs the batch as parallel parts -- config.split_batch -- whose '
                                  'quarter-size launches overlap; conv1 of the next layer rides in this launch when the key says +next_conv1x1).  '
-                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r05_kernel_stats.csv',
+                                 'rocprofv3 --kernel-trace --stats of the same command: profiles/r06_kernel_stats.csv',
                         algorithmic_bytes=timer.bytes.get(dom), launches_per_step=kern[dom]['n'] // 3,
                         note='exact-fp32 v_mfma_f32_32x32x2_f32 path' if precision == L.PREC_F32 else
                              f'fp32 accuracy via 3-term {args.precision[:-2]} split on v_mfma_f32_32x32x16_{args.precision[:-2]}: peak = 2500 TF dense / 3 MFMA products per '

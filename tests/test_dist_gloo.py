@@ -148,7 +148,7 @@ def test_predict_range_error_leaves_no_output_and_no_threads(tmp_path, monkeypat
 
     def second_bucket_out_of_range(self, device=None, reduce=None):
         calls.append(1)
-        if len(calls) == 2:                       # buckets are visited in sorted shape order: (32, 32) passes, (40, 56) "overflowed"
+        if len(calls) == 2:                       # buckets are visited largest padded shape first: (40, 56) passes, (32, 32) "overflowed"
             raise L.LamaRangeError('test: out of range')
         return real(self, device, reduce)
 
@@ -157,7 +157,7 @@ def test_predict_range_error_leaves_no_output_and_no_threads(tmp_path, monkeypat
     with pytest.raises(L.LamaRangeError):
         P.predict(model, items, indir, outdir, pad_mod=8, batch_size=2, device='cpu', io_threads=2)
     left = sorted(os.path.relpath(os.path.join(d, f), outdir) for d, _, fs in os.walk(outdir) for f in fs)
-    assert left == ['a/img1_mask000.png', 'img4_mask000.png'], left          # the two 32 x 32 images of the bucket that passed
+    assert left == ['a/img3_mask000.png', 'img0_mask000.png', 'img2_mask000.png'], left          # the three 40 x 56 images of the bucket that passed
     assert threading.active_count() <= before and gen.defer_range_check is False
 
 
