@@ -43,7 +43,7 @@ DEFAULTS = {'model.checkpoint': 'best.ckpt', 'dataset.img_suffix': '.png', 'data
 # ----------------------------------------------------------------------------------------------------------------
 
 # keys of configs/prediction/default.yaml this driver honours; anything else is rejected instead of silently ignored
-KNOWN_KEYS = set(DEFAULTS) | {'model.path', 'indir', 'outdir', 'device', 'dataset.kind', 'refine', 'profile',
+KNOWN_KEYS = set(DEFAULTS) | {'model.path', 'indir', 'outdir', 'device', 'dataset.kind', 'dataset.scale_factor', 'refine', 'profile',
                               'refiner.gpu_ids', 'refiner.modulo', 'refiner.n_iters', 'refiner.lr', 'refiner.min_side',
                               'refiner.max_scales', 'refiner.px_budget'}
 REFINER_DEFAULTS = {'refiner.gpu_ids': '0,', 'refiner.modulo': 8, 'refiner.n_iters': 15, 'refiner.lr': 0.002, 'refiner.min_side': 512,
@@ -57,7 +57,7 @@ STRING_KEYS = {'model.path', 'model.checkpoint', 'indir', 'outdir', 'device', 'd
 BOOL_KEYS = {'refine', 'profile'}
 INT_KEYS = {'dataset.pad_out_to_modulo', 'batch_size', 'io_threads', 'refiner.modulo', 'refiner.n_iters', 'refiner.min_side', 'refiner.max_scales',
             'refiner.px_budget'}
-FLOAT_KEYS = {'refiner.lr'}
+FLOAT_KEYS = {'refiner.lr', 'dataset.scale_factor'}
 
 
 def _parse_value(k: str, v: str):
@@ -88,8 +88,6 @@ def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
             raise SystemExit(f'expected key=value, got {a!r}')
         k, v = a.split('=', 1)
         if k not in KNOWN_KEYS:
-            if k == 'dataset.scale_factor':
-                raise NotImplementedError('dataset.scale_factor (evaluation/data.py:74-77, cv2 resize) is not implemented')
             raise SystemExit(f'unknown option {k!r}; known: {sorted(KNOWN_KEYS)}')
         cfg[k] = _parse_value(k, v)
     for need in ('model.path', 'indir', 'outdir'):
@@ -101,6 +99,8 @@ def parse_overrides(argv: Sequence[str]) -> Dict[str, object]:
         raise NotImplementedError(f"dataset.kind={cfg['dataset.kind']} (only the default InpaintingDataset of bin/predict.py)")
     if cfg.get('out_key', 'inpainted') not in ('inpainted', 'predicted_image'):
         raise SystemExit(f"out_key={cfg['out_key']!r}: the predict_only forward (trainers/default.py:56-71) produces 'inpainted' and 'predicted_image'")
+    if cfg.get('dataset.scale_factor') is not None and not cfg['dataset.scale_factor'] > 0:
+        raise SystemExit(f"dataset.scale_factor={cfg['dataset.scale_factor']!r}: a positive factor (evaluation/data.py:74-77)")
     return cfg
 
 
@@ -129,6 +129,132 @@ def pad_img_to_modulo(img: np.ndarray, mod: int) -> np.ndarray:
     return np.pad(img, ((0, 0), (0, ceil_modulo(h, mod) - h), (0, ceil_modulo(w, mod) - w)), mode='symmetric')
 
 
+# ---- dataset.scale_factor (evaluation/data.py:42-55,74-77): cv2.resize(img, dsize=None, fx=f, fy=f) with INTER_AREA on the float image and
+# INTER_NEAREST on the float mask.  cv2 is not in this image, so this is a restatement of OpenCV 4's imgproc/resize.cpp from its published
+# algorithm -- PARITY UNPINNED (no cv2 here to generate vectors from): the index / weight tables and the float32 accumulation order follow
+# resize.cpp (computeResizeAreaTab + ResizeArea_Invoker; resizeAreaFast_Invoker's four-at-a-time sums; the INTER_AREA-upscaling coefficients of
+# the linear path; resizeNN's floor(x / f) taps), known-answer tests in tests/test_scale_factor.py.  Host code on purpose: it is the data loader.
+
+def scaled_size(h: int, w: int, factor: float) -> Tuple[int, int]:
+    """dsize of cv::resize(dsize=None, fx, fy): saturate_cast<int>(size * f) = round half to even."""
+    return int(round(h * factor)), int(round(w * factor))
+
+
+def _area_taps(ssize: int, dsize: int, scale: float):
+    """computeResizeAreaTab: per destination index the source taps and their float32 weights, padded to a common tap count with weight 0."""
+    import math
+    taps = []
+    for d in range(dsize):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, ssize - f1)
+        s1, s2 = math.ceil(f1), math.floor(f2)
+        s2 = min(s2, ssize - 1)
+        s1 = min(s1, s2)
+        t = []
+        if s1 - f1 > 1e-3:
+            t.append((s1 - 1, np.float32((s1 - f1) / cell)))
+        for sx in range(s1, s2):
+            t.append((sx, np.float32(1.0 / cell)))
+        if f2 - s2 > 1e-3:
+            t.append((s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+        taps.append(t)
+    T = max(len(t) for t in taps)
+    idx = np.zeros((dsize, T), np.int64)
+    wt = np.zeros((dsize, T), np.float32)
+    for d, t in enumerate(taps):
+        for k, (sx, a) in enumerate(t):
+            idx[d, k], wt[d, k] = sx, a
+    return idx, wt
+
+
+def _resize_area(img: np.ndarray, factor: float) -> np.ndarray:
+    """INTER_AREA of a float32 [H, W] or [H, W, C] image by ``factor`` in both directions."""
+    import math
+    a = np.ascontiguousarray(img, dtype=np.float32)
+    H, W = a.shape[:2]
+    dh, dw = scaled_size(H, W, factor)
+    if dh <= 0 or dw <= 0:
+        raise L.LamaError(f'scale_factor {factor}: a {W}x{H} image scales to nothing')
+    scale = 1.0 / factor
+    if scale >= 1.0:                                            # shrinking: true area averaging
+        isc = int(round(scale))
+        if abs(scale - isc) < np.finfo(np.float64).eps:         # integer factor: resizeAreaFast -- box sums in groups of four, * 1 / area
+            # destination pixels whose box would leave the image are cut off by dsize = round(size * f) (<= size / isc only when it divides)
+            dh2, dw2 = min(dh, H // isc), min(dw, W // isc)
+            box = [a[sy:sy + dh2 * isc:isc, sx:sx + dw2 * isc:isc] for sy in range(isc) for sx in range(isc)]
+            acc = np.zeros_like(box[0])
+            k, area = 0, isc * isc
+            while k <= area - 4:
+                acc = acc + (((box[k] + box[k + 1]) + box[k + 2]) + box[k + 3])
+                k += 4
+            while k < area:
+                acc = acc + box[k]
+                k += 1
+            out = acc * np.float32(1.0 / area)
+            if (dh2, dw2) != (dh, dw):                          # (x.5 rounded up: the partial last boxes average the pixels inside the image)
+                full = np.zeros((dh, dw) + a.shape[2:], np.float32)
+                full[:dh2, :dw2] = out
+                for yy in range(dh):
+                    for xx in range(dw):
+                        if yy >= dh2 or xx >= dw2:
+                            blk = a[yy * isc:min((yy + 1) * isc, H), xx * isc:min((xx + 1) * isc, W)]
+                            px = blk.reshape(-1, *a.shape[2:])                   # resizeAreaFast's border loop: sum / count of the pixels inside
+                            acc1 = np.zeros(a.shape[2:], np.float32)
+                            for v in px:
+                                acc1 = acc1 + v
+                            full[yy, xx] = acc1 / np.float32(len(px))
+                out = full
+            return out
+        xi, xw = _area_taps(W, dw, scale)
+        yi, yw = _area_taps(H, dh, scale)
+        ex = (slice(None),) * 2 + (None,) * (a.ndim - 2)
+        buf = np.zeros((H, dw) + a.shape[2:], np.float32)      # the x pass of every source row: buf[dx] += S[sx] * alpha, taps in table order
+        for t in range(xi.shape[1]):
+            buf = buf + a[:, xi[:, t]] * xw[None, :, t][ex] if t else a[:, xi[:, t]] * xw[None, :, t][ex]
+        out = np.zeros((dh, dw) + a.shape[2:], np.float32)     # the y pass: sum[dx] = beta * buf, then += for the following rows
+        for t in range(yi.shape[1]):
+            term = buf[yi[:, t]] * yw[:, t][(slice(None), None) + (None,) * (a.ndim - 2)]
+            out = out + term if t else term
+        return out
+    # enlarging with INTER_AREA = the linear path with area coefficients: sx = floor(dx * scale), fx = (dx + 1) - (sx + 1) * f, kept in [0, 1)
+    def coef(ssize, dsize):
+        sx = np.floor(np.arange(dsize) * scale).astype(np.int64)
+        fx = ((np.arange(dsize) + 1) - (sx + 1) * factor).astype(np.float32)
+        fx = np.where(fx <= 0, np.float32(0), fx - np.floor(fx)).astype(np.float32)
+        lo = sx < 0
+        fx[lo], sx[lo] = 0, 0
+        hi = sx >= ssize - 1
+        fx[hi], sx[hi] = 0, ssize - 1
+        return sx, np.minimum(sx + 1, ssize - 1), (np.float32(1) - fx).astype(np.float32), fx
+    x0, x1, ax0, ax1 = coef(W, dw)
+    y0, y1, ay0, ay1 = coef(H, dh)
+    ex = (None, slice(None)) + (None,) * (a.ndim - 2)
+    rows = a[:, x0] * ax0[ex] + a[:, x1] * ax1[ex]
+    ey = (slice(None), None) + (None,) * (a.ndim - 2)
+    return (rows[y0] * ay0[ey] + rows[y1] * ay1[ey]).astype(np.float32)
+
+
+def _resize_nearest(img: np.ndarray, factor: float) -> np.ndarray:
+    """INTER_NEAREST: tap min(floor(d / f), size - 1) in each direction (resizeNN)."""
+    H, W = img.shape[:2]
+    dh, dw = scaled_size(H, W, factor)
+    if dh <= 0 or dw <= 0:
+        raise L.LamaError(f'scale_factor {factor}: a {W}x{H} image scales to nothing')
+    inv = 1.0 / factor
+    ys = np.minimum(np.floor(np.arange(dh) * inv).astype(np.int64), H - 1)
+    xs = np.minimum(np.floor(np.arange(dw) * inv).astype(np.int64), W - 1)
+    return np.ascontiguousarray(img[ys][:, xs])
+
+
+def scale_image(img: np.ndarray, factor: float, interpolation: str = 'area') -> np.ndarray:
+    """evaluation/data.py:42-55: a float32 [C,H,W] image through cv2.resize(fx=fy=factor) and back to [C,H',W'] ('area' = cv2.INTER_AREA, the
+    default; 'nearest' = cv2.INTER_NEAREST, what InpaintingDataset uses for the mask)."""
+    hwc = img[0] if img.shape[0] == 1 else np.transpose(img, (1, 2, 0))
+    out = _resize_nearest(hwc, factor) if interpolation == 'nearest' else _resize_area(hwc, factor)
+    return out[None, ...] if out.ndim == 2 else np.transpose(out, (2, 0, 1))
+
+
 def load_item_u8(mask_path: str, img_path: str):
     """The same pair as it is on disk: (u8 image [H,W,3], u8 mask [H,W], (H, W)).  ``load_image``'s / 255, ``pad_img_to_modulo`` and
     bin/predict.py:84's ``mask > 0`` happen on the device (lama_mask_compose_u8_fwd, ABI v110): the host only decodes."""
@@ -140,13 +266,17 @@ def load_item_u8(mask_path: str, img_path: str):
     return image, mask, tuple(image.shape[:2])
 
 
-def load_item(mask_path: str, img_path: str, pad_mod: int):
-    """InpaintingDataset.__getitem__, evaluation/data.py:69-83 -> (image [3,H',W'], mask [1,H',W'], (H, W))."""
+def load_item(mask_path: str, img_path: str, pad_mod: int, scale_factor: Optional[float] = None):
+    """InpaintingDataset.__getitem__, evaluation/data.py:69-83 -> (image [3,H',W'], mask [1,H',W'], (H, W)): ``scale_factor`` rescales the image
+    (INTER_AREA) and the mask (INTER_NEAREST) before the padding, and (H, W) = ``unpad_to_size`` is the rescaled size (data.py:74-79)."""
     image = load_image(img_path, 'RGB')
     mask = load_image(mask_path, 'L')[None, ...]
+    if tuple(mask.shape[1:]) != tuple(image.shape[1:]):
+        raise L.LamaError(f'{mask_path}: mask is {mask.shape[2]}x{mask.shape[1]} but {img_path} is {image.shape[2]}x{image.shape[1]}')
+    if scale_factor is not None:
+        image = scale_image(image, scale_factor)
+        mask = scale_image(mask, scale_factor, interpolation='nearest')
     hw = image.shape[1:]
-    if tuple(mask.shape[1:]) != tuple(hw):
-        raise L.LamaError(f'{mask_path}: mask is {mask.shape[2]}x{mask.shape[1]} but {img_path} is {hw[1]}x{hw[0]}')
     if pad_mod and pad_mod > 1:
         image, mask = pad_img_to_modulo(image, pad_mod), pad_img_to_modulo(mask, pad_mod)
     return image, mask, hw
@@ -370,6 +500,19 @@ class HostFedStep:
     def put(self, p: int, j: int, image: Optional[np.ndarray], mask: Optional[np.ndarray]):
         """``u8_input``: image j of host set p = a decoded u8 HWC image [h,w,3] + u8 mask [h,w] (top-left corner of the slot), or None: an empty
         slot of a partial batch."""
+        if not self.u8_input:
+            # fp32 NCHW form (dataset.scale_factor: the rescaled image is not u8 any more): image [3,Hp,Wp] / mask [1,Hp,Wp] float32 as
+            # ``load_item`` returns them, already padded; an empty slot is zeros
+            hi, hm = self.h_img[p].numpy(), self.h_mask[p].numpy()
+            if image is None:
+                hi[j] = 0
+                hm[j] = 0
+                return
+            if tuple(image.shape) != (3, self.Hp, self.Wp) or tuple(mask.shape) != (1, self.Hp, self.Wp):
+                raise L.LamaError(f'image {tuple(image.shape)} / mask {tuple(mask.shape)}: padded [3,{self.Hp},{self.Wp}] / [1,{self.Hp},{self.Wp}] float32')
+            hi[j] = image
+            hm[j] = mask
+            return
         sz = self.h_sizes[p].numpy()
         if image is None:
             sz[j] = (0, 0)
@@ -557,8 +700,10 @@ class HostFedStep:
 
 def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[str, str]], indir: str, outdir: str, *,
             pad_mod: int = 8, batch_size: int = 8, out_ext: str = '.png', device='cuda', rank: int = 0, world: int = 1,
-            dist=None, io_threads: int = 8, out_key: str = 'inpainted') -> int:
+            dist=None, io_threads: int = 8, out_key: str = 'inpainted', scale_factor: Optional[float] = None) -> int:
     """Run every (mask, image) pair through ``model`` and write the results (rank 0).  Returns the number of images written.
+    ``scale_factor`` = ``dataset.scale_factor`` (evaluation/data.py:74-77): every image / mask is rescaled on the host before the padding, the
+    step is then fed with fp32 tensors and the results have the rescaled size.
 
     Host pipeline: the PNGs of round r + 1 are decoded / padded on the thread pool while round r computes, results are
     written on the same pool; a partial last batch of a bucket is zero-padded to ``batch_size`` so that it replays the bucket's
@@ -571,7 +716,7 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
         for _attempt in range(2):
             try:
                 return _predict_once(model, items, indir, outdir, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext, device=device,
-                                     rank=rank, world=world, dist=dist, io_threads=io_threads, out_key=out_key)
+                                     rank=rank, world=world, dist=dist, io_threads=io_threads, out_key=out_key, scale_factor=scale_factor)
             except _RangeRestart:
                 continue                     # the generator switched to the 3-term bf16 split (every rank alike): all images again
         raise L.LamaError('range restart did not converge')
@@ -579,13 +724,13 @@ def predict(model: trainers.DefaultInpaintingTrainingModule, items: List[Tuple[s
         gen.defer_range_check = keep
 
 
-def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, device, rank, world, dist, io_threads, out_key='inpainted') -> int:
+def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, device, rank, world, dist, io_threads, out_key='inpainted', scale_factor=None) -> int:
     from PIL import Image
 
     def header_size(item):                   # padded shape from the IMAGE's PNG header only: every rank builds the same plan
         with Image.open(item[1]) as im:
             w, h = im.size
-        return h, w
+        return (h, w) if scale_factor is None else scaled_size(h, w, scale_factor)
 
     lib = model.generator._exec.lib
     pool = ThreadPoolExecutor(io_threads)
@@ -597,13 +742,14 @@ def _predict_once(model, items, indir, outdir, *, pad_mod, batch_size, out_ext, 
         shapes = [(ceil_modulo(h, pad_mod), ceil_modulo(w, pad_mod)) if pad_mod and pad_mod > 1 else (h, w) for h, w in sizes]
         rounds = plan_rounds(shapes, batch_size, world)
         return _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, pad_mod=pad_mod, batch_size=batch_size, out_ext=out_ext,
-                               device=device, rank=rank, world=world, dist=dist, out_key=out_key, fast=fast)
+                               device=device, rank=rank, world=world, dist=dist, out_key=out_key, fast=fast, scale_factor=scale_factor)
     finally:
         fast.shutdown()
         pool.shutdown()                      # on every exit path (a raise out of a bucket included): no worker thread outlives the call
 
 
-def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist, out_key='inpainted', fast=None) -> int:
+def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pad_mod, batch_size, out_ext, device, rank, world, dist, out_key='inpainted', fast=None,
+                    scale_factor=None) -> int:
     """The rounds of one attempt.  Per bucket (padded shape) a ``HostFedStep``: round k computes from device input set k & 1 while the SAME graph
     launch uploads round k + 1's decoded images into the other set and (one rank) downloads round k - 1's u8 results; the host fills the
     pinned set of round k + 1 and queues round k - 2's PNG writes while round k runs.  Several ranks: the results go through the one
@@ -623,7 +769,10 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
 
     def submit_loads(r):
         if r < len(rounds) and r not in loads:
-            loads[r] = [pool.submit(load_item_u8, *items[i]) for i in rounds[r]['batches'][rank]]      # decode only: / 255, padding, mask > 0 run on the device
+            if scale_factor is None:
+                loads[r] = [pool.submit(load_item_u8, *items[i]) for i in rounds[r]['batches'][rank]]  # decode only: / 255, padding, mask > 0 run on the device
+            else:                                                                                      # data.py:69-83 on the host: decode, / 255, rescale, pad
+                loads[r] = [pool.submit(load_item, *items[i], pad_mod, scale_factor) for i in rounds[r]['batches'][rank]]
 
     snapped = [_Latch(), _Latch()]           # per pinned result set: the workers that still copy their image out of it
 
@@ -652,7 +801,8 @@ def _predict_rounds(model, items, indir, outdir, rounds, sizes, pool, lib, *, pa
             r1 += 1
         K = r1 - r0
         t_ = time.perf_counter()
-        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS), capture=(K >= CAPTURE_MIN_ROUNDS), out_key=out_key)
+        hs = HostFedStep(model, batch_size, Hp, Wp, device, drain=(world == 1), tune=(K >= TUNE_MIN_ROUNDS), capture=(K >= CAPTURE_MIN_ROUNDS), out_key=out_key,
+                         u8_input=(scale_factor is None))
         LOOP_TIMES['bucket_setup'] = LOOP_TIMES.get('bucket_setup', 0.0) + time.perf_counter() - t_
         if PROFILE_SPANS:
             hs.span_events = []
@@ -785,7 +935,7 @@ def predict_refine(model, items: List[Tuple[str, str]], indir: str, outdir: str,
     futures, written = [], 0
     for i in range(rank, len(items), world):
         mask_path, img_path = items[i]
-        image, mask, (h, w) = load_item(mask_path, img_path, pad_mod)
+        image, mask, (h, w) = load_item(mask_path, img_path, pad_mod, cfg.get('dataset.scale_factor'))
         batch = dict(image=torch.from_numpy(image)[None].to(device), mask=torch.from_numpy(mask)[None].to(device),
                      unpad_to_size=[torch.tensor([h]), torch.tensor([w])])
         # bin/predict.py:75-81: the refine branch hands the RAW grayscale mask to refine_predict (line 84's binarisation belongs to the
@@ -838,7 +988,8 @@ def main(argv: Optional[Sequence[str]] = None) -> int:
         PROFILE_SPANS = True
     t0 = time.perf_counter()
     n = predict(model, items, indir, cfg['outdir'], pad_mod=int(cfg['dataset.pad_out_to_modulo']), batch_size=int(cfg['batch_size']),
-                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist, io_threads=int(cfg['io_threads']), out_key=cfg['out_key'])
+                out_ext=cfg['out_ext'], device=device, rank=rank, world=world, dist=dist, io_threads=int(cfg['io_threads']), out_key=cfg['out_key'],
+                scale_factor=cfg.get('dataset.scale_factor'))
     dt = time.perf_counter() - t0
     if rank == 0:
         # (the loop's own wall time: plan build + graph capture of every shape bucket, PNG decode, upload, compute, download, PNG encode + write)

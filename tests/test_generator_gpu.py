@@ -352,6 +352,18 @@ def test_predict_cli_end_to_end(tmp_path):
         _, u8 = O.predict_one(O.load_image(img_path, 'RGB'), O.load_image(mask_path, 'L'), sdg, cfg)
         assert got.shape == u8.shape
         assert np.abs(got.astype(int) - u8.astype(int)).max() <= 1, rel
+    # dataset.scale_factor (evaluation/data.py:74-77): image (INTER_AREA) and mask (INTER_NEAREST) rescaled on the host, fp32 tensors up, results at
+    # the rescaled size (cv2 itself is not in this image: tests/test_scale_factor.py)
+    out2 = tmp_path / 'out_scaled'
+    assert P.main([f'model.path={mdir}', f'indir={indir}', f'outdir={out2}', 'batch_size=2', 'dataset.scale_factor=0.75']) == 0
+    for mask_path, img_path in items:
+        rel = os.path.splitext(mask_path[len(str(indir)) + 1:])[0] + '.png'
+        got = np.array(Image.open(out2 / rel))
+        image = P.scale_image(O.load_image(img_path, 'RGB'), 0.75)
+        mask = P.scale_image(O.load_image(mask_path, 'L')[None], 0.75, interpolation='nearest')[0]
+        _, u8 = O.predict_one(image, mask, sdg, cfg)
+        assert got.shape == u8.shape == (image.shape[1], image.shape[2], 3)
+        assert np.abs(got.astype(int) - u8.astype(int)).max() <= 1, rel
 
 
 def test_long_plane_two_pass_fft(big):
