@@ -231,6 +231,35 @@ def test_rfft2_irfft2(lib, hw):
     assert torch.allclose(y.cpu(), ref2, atol=tol, rtol=1e-4), float((y.cpu() - ref2).abs().max())
 
 
+def test_rfft2_irfft2_every_length_up_to_256(lib):
+    """Every plane length the /8 bottleneck of a padded input can have (evaluation/data.py:29-33 pads to multiples of 8 only): h = 2 .. 256 paired with
+    a w that walks the same range in another order -- every mixed-radix plan (composite radices, 11, 13, the pair-symmetric pass of larger primes, the
+    two-launch form beyond the LDS) as rows AND as columns, against torch.fft on the host."""
+    st = torch.cuda.current_stream().cuda_stream
+    B, Cn = 1, 2
+    worst = (0.0, None)
+    for h in range(2, 257):
+        w = 2 + (h * 97) % 255                                   # 97 is coprime to 255: w takes every value of 2 .. 256 once
+        g = torch.Generator().manual_seed(h)
+        x = torch.randn(B, Cn, h, w, generator=g)
+        xd = x.to(DEV)
+        spec = torch.zeros(B, 2 * Cn, h, w // 2 + 1, device=DEV)
+        ws = torch.zeros(max(lib.fft_workspace_bytes(B, Cn, h, w), 4) // 4, device=DEV)
+        lib.rfft2(L.view(xd), L.view(spec), B, ws, stream=st)
+        ref = _spec_ref(x)
+        e1 = float((spec.cpu() - ref).abs().max())
+        spec2 = torch.relu(torch.randn(B, 2 * Cn, h, w // 2 + 1, generator=g))
+        resid = torch.randn(B, Cn, h, w, generator=g)
+        y = torch.zeros(B, Cn, h, w, device=DEV)
+        s2d, rd = spec2.to(DEV), resid.to(DEV)                    # (kept alive: L.view holds raw pointers)
+        lib.irfft2(L.view(s2d), L.view(rd), L.view(y), B, ws, stream=st)
+        e2 = float((y.cpu() - (resid + _inv_ref(spec2, h, w))).abs().max())
+        if max(e1, e2) > worst[0]:
+            worst = (max(e1, e2), (h, w))
+        assert e1 < 2e-4 and e2 < 2e-4, (h, w, e1, e2)
+    print('worst', worst)
+
+
 def test_fft_masked_entries(lib):
     """lama_rfft2_masked_fwd / lama_irfft2_masked_fwd (v108) on 256 x 256 planes against transform + separate mask, channel views of wider buffers."""
     g = torch.Generator().manual_seed(77)
