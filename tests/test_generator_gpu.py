@@ -299,6 +299,30 @@ def test_odd_sized_input_generic_fft(big):
     assert float((gen(x.cuda()).cpu() - ref).abs().max()) < TOL
 
 
+SWEEP_SHAPES = [(1, 16, 16), (1, 16, 24), (1, 32, 64), (2, 72, 104), (3, 136, 136), (1, 200, 328), (2, 312, 120), (1, 400, 408), (1, 512, 520), (1, 520, 512),
+                (1, 24, 512), (1, 512, 24), (5, 96, 160), (7, 64, 72), (9, 40, 48), (1, 88, 1048), (2, 1024, 16), (1, 640, 808)]
+
+
+def test_biglama_shape_sweep(big):
+    """Padded shapes real directories produce (any multiple of 8 per side, evaluation/data.py:29-33), chosen to cross the geometry decisions of the
+    kernels: bottleneck planes of 2 x 2 ... 80 x 101 (mixed-radix plans incl. primes, planes narrower than a Winograd segment or a 128-pixel tile,
+    launches of fewer / more than one round of workgroups, widths that are not multiples of 32 for the stem / head / transposed convs, odd batches).
+    Every shape against the fp32 oracle, first call (plan build) and the replay of the captured plan."""
+    cfg, sd, gen, TOL = big
+    if gen.precision != L.PREC_F16X3:
+        pytest.skip('one precision is enough for this sweep')
+    for B, H, W in SWEEP_SHAPES:
+        batch = O.make_synthetic_batch(B, H, W, seed=H * 7 + W)
+        x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+        with torch.no_grad():
+            ref = O.generator_forward(x, sd, cfg)
+        xd = x.cuda()
+        e1 = float((gen(xd).cpu() - ref).abs().max())
+        e2 = float((gen(xd).cpu() - ref).abs().max())
+        gen._plans.clear()
+        assert e1 < TOL and e2 < TOL, (B, H, W, e1, e2)
+
+
 def test_photo_sized_input(big):
     """1080 x 1920 (a photo; bottleneck planes 135 x 240: the generic DFT kernels with their one Cooley-Tukey split per length, and 254
     pixel tiles per launch, i.e. conv1 riding in the global-branch epilogues) against the oracle, at 1.5x the 512^2 tolerance like

@@ -297,6 +297,43 @@ def test_rear_gradients_strict_on_256x256_planes(big2):
     assert rel < 5e-5 and mx < 2.5e-4, (rel, mx)
 
 
+@pytest.mark.parametrize('hw', [(1344, 1344), (1000, 1504)], ids=['planes168x168_default_budget', 'planes125x188_prime47'])
+def test_rear_gradients_strict_on_non_power_of_two_planes(big2, hw):
+    """The reverse pass where the reference's DEFAULT refinement runs it (configs/prediction/default.yaml:24: px_budget 1.8 M rescales a large image to
+    ~1341^2 -> padded 1344^2, bottleneck planes 168 x 168 = 2^3 3 7; evaluation/refinement.py:203-211), and at a photo plane with a large prime
+    (1000 x 1504 -> 125 x 188 = 5^3 x 4 47): the adjoints of the mixed-radix transforms (fft_mr_dev.inc), the dgrad convs at planes that are no
+    multiple of a tile, the transposed-conv adjoints at ragged widths.  Same construction as test_rear_gradients_strict_on_256x256_planes: two
+    FFCResnetBlocks at big-lama's channel counts + the three ConvTranspose2d adjoints + the head, exact fp32 both ways, torch autograd through the
+    oracle with the ReLU masks of the HIP tape -- only rounding separates the two."""
+    from tests import masked_oracle as MO
+    cfg, sd = big2
+    gen = make_generator(None, kind='ffc_resnet', **cfg)
+    gen.load_state_dict(sd, strict=True)
+    gen.cuda().set_precision(L.PREC_F32)
+    fri = R.first_resblock_index(cfg)
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    H, W = hw
+    batch = O.make_synthetic_batch(1, H, W, seed=10)
+    x = torch.cat([batch['image'] * (1 - batch['mask']), batch['mask']], 1)
+    with torch.no_grad():
+        z1, z2 = O.run_layers(x, sd, cfg, 0, fri)
+    assert tuple(z1.shape[-2:]) == (H // 8, W // 8)
+    rear = RearPass(gen, fri, bwd_precision=L.PREC_F32)
+    pred = rear.forward(torch.cat([z1, z2], 1).contiguous().to(DEV))
+    gw = torch.randn(pred.shape, generator=torch.Generator().manual_seed(7)) / pred.numel()
+    g = rear.backward(gw.contiguous().to(DEV)).cpu()
+    masks = MO.tape_masks(rear)
+    assert len(masks) == 2 * 2 * 4 + 3
+    pred_ref, gref = MO.rear_gradient(z1, z2, sd, cfg, fri, gw, masks)
+    rel = float((g - gref).norm() / gref.norm())
+    mx = float((g - gref).abs().max() / gref.abs().max())
+    perr = float((pred.cpu() - pred_ref).abs().max())
+    print(f'2 blocks, {H} x {W} (planes {H // 8} x {W // 8}; masked FFT entries: {rear._plan["sh"].get("fft_mask", True)}): gradient rel L2 {rel:.2e} '
+          f'(max / gmax {mx:.2e}), pred max-abs {perr:.2e}', flush=True)
+    assert perr < 1e-4, perr
+    assert rel < 5e-5 and mx < 2.5e-4, (rel, mx)
+
+
 @pytest.mark.parametrize('case', [(1, 64, 64), (1, 30, 50), (3, 128, 256)])
 def test_reflect_pad_adjoint_fused_matches_separate_launches(case):
     """lama_reflect_pad_bwd_fused (v108) against fold + add + act_bwd as separate launches, on channel views of the 512-channel state
