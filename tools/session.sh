@@ -13,6 +13,7 @@
 #   overlap                    rocprofv3 kernel trace of tools/split_trace.py: which kernels ran side by side (one-part vs split plan) -> overlap_summary.txt
 #   pmc:<kprobe names>         rocprofv3 --pmc passes (one counter set per run) over tools/kprobe.py f16x3 <names>  -> pmc_<names>/
 #   pmcbench                   FETCH_SIZE / WRITE_SIZE passes over the quick bench itself (traffic IN the pipeline; under the profiler the generator keeps its one-part plan: verify_split) -> pmc_bench_*.txt, pmc.json
+#   mfmabench                  SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE passes over the quick bench (run `stats` first: kernel_stats.csv gives the durations) -> mfma_util.txt
 #   shapes                     the other single-GPU shapes (4x1024, 4x256, 1x512, 1x2048)
 #   kbench                     per-kernel timings, operands rotated out of the Infinity Cache (KBENCH_ROT=6)
 #   power                      MFMA sustained-rate micro-benchmark (tools/ubench/mfma_power.hip)
@@ -69,6 +70,12 @@ for STEP in "$@"; do
               (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg --no-host-fed-leg --split-batch 1 > $ROOT/$O/pmcb_$CNT.log 2>&1)
               f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f > $O/pmc_bench_$CNT.txt && grep -E "conv_wr_kernel|wino_|gemm1x1_wk|fft2_ip64|convt2|head7|stem7" $O/pmc_bench_$CNT.txt | cut -c1-60,118-200 | tee -a $O/summary.txt; rm -rf $O/pmcb_$CNT; done
               python tools/pmc_bench_to_json.py $O/pmc.json $O/pmc_bench_FETCH_SIZE.txt $O/pmc_bench_WRITE_SIZE.txt | tee -a $O/summary.txt ;;
+    mfmabench) # MFMA utilisation IN the pipeline: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the SIMDs: 32 per v_mfma_f32_32x32x16) and GRBM_GUI_ACTIVE
+              # (clock cycles of the launch) in passes of their own over the one-part quick bench; tools/mfma_util.py turns them into busy fraction + effective clock
+              for CNT in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES; do
+              (cd /tmp && timeout 600 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $ROOT/$O/pmcb_$CNT -o pmc -- python $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-f32-leg --no-eager-leg --no-host-fed-leg --split-batch 1 > $ROOT/$O/pmcb_$CNT.log 2>&1)
+              f=$(find $O/pmcb_$CNT -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f > $O/pmc_bench_$CNT.txt; rm -rf $O/pmcb_$CNT; done
+              python tools/mfma_util.py $O/pmc_bench_SQ_VALU_MFMA_BUSY_CYCLES.txt $O/pmc_bench_GRBM_GUI_ACTIVE.txt $O/kernel_stats.csv | tee $O/mfma_util.txt | tee -a $O/summary.txt ;;
     shapes) for cfg in "4 1024" "4 256" "1 512" "1 2048"; do set -- $cfg
               LAMA_BENCH_BATCH=$1 LAMA_BENCH_RES=$2 timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-f32-leg --no-eager-leg 2>/dev/null | tail -1 | python -c "
 import sys,json
