@@ -35,7 +35,7 @@ _SLOW_FIRST = ('test_refine_oracle_pin', 'test_inplace_residual_and_aliased_t', 
                'test_infer_one_scale_matches_autograd_adam', 'test_biglama_shape_matches_reference', 'test_predict_world2_gloo', 'test_conv1_rides_in_the_global',
                'test_f16_split_overflow_falls_back', 'test_deferred_range_check_has_no_read_back', 'test_ffc_units_at_biglama_channel_counts',
                'test_deferred_winograd_output_transform_plan', 'test_refine_predict_two_scales', 'test_generator_fp16_activation_path',
-               'test_predict_range_error_leaves', 'test_host_fed_step_double_buffering')
+               'test_predict_range_error_leaves', 'test_host_fed_step_double_buffering', 'test_predict_loop_with_scale_factor')
 
 
 def pytest_collection_modifyitems(config, items):
