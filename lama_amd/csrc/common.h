@@ -100,6 +100,17 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 #define LAMA_F16_RESIDUAL_LO(d, packed, x) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(x))
 #define LAMA_F16_RESIDUAL_HI(d, packed, x) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(packed), "v"(x))
 #endif
+// The lo word of an fp16 (hi, lo) split in TWO VALU instructions (round 6, fourth session): lo = { fp16(a - float(hi.lo)), fp16(b - float(hi.hi)) }.
+// v_fma_mixlo_f16 / v_fma_mixhi_f16 form the fp32 residual (exact: |x - fp16(x)| <= half an fp16 ulp of x = at most 13 significant bits) and round it to
+// fp16 INTO the low / high half of the destination, keeping its other half -- the residual + v_cvt_pk_f16_f32 of the three-instruction form in one.  Same
+// bits: the intermediate fp32 residual is exact, so one rounding (RNE) either way.  (tests/hipemu overrides it for the host build.)
+#ifndef LAMA_F16_SPLIT_LO
+#define LAMA_F16_SPLIT_LO(lo, packed, a, b)                                                                                         \
+    do {                                                                                                                            \
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(packed), "v"(a));                    \
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(packed), "v"(b));                    \
+    } while (0)
+#endif
 
 // LDS hand-off between the lanes of ONE wave (wave-private LDS regions, no workgroup barrier): the LDS pipe executes a wave's
 // instructions in order, so only the compiler has to be kept from moving accesses across this point.  (tests/hipemu maps it

@@ -342,6 +342,14 @@ static inline float hipemu_f16_residual(unsigned packed, float x, int hi) {
 }
 #define LAMA_F16_RESIDUAL_LO(d, packed, x) ((d) = hipemu_f16_residual(packed, x, 0))
 #define LAMA_F16_RESIDUAL_HI(d, packed, x) ((d) = hipemu_f16_residual(packed, x, 1))
+static inline unsigned hipemu_f16_split_lo(unsigned packed, float a, float b) {      // v_fma_mixlo_f16 + v_fma_mixhi_f16: the residuals rounded to fp16 (RNE) and packed
+    _Float16 l0 = (_Float16)hipemu_f16_residual(packed, a, 0), l1 = (_Float16)hipemu_f16_residual(packed, b, 1);
+    unsigned short u0, u1;
+    memcpy(&u0, &l0, 2);
+    memcpy(&u1, &l1, 2);
+    return (unsigned)u0 | ((unsigned)u1 << 16);
+}
+#define LAMA_F16_SPLIT_LO(lo, packed, a, b) ((lo) = hipemu_f16_split_lo(packed, a, b))
 #define LAMA_WAVE_UNIFORM(x) (x)
 #define LAMA_WAVE_SYNC() hipemu::wave_barrier()
 #define LAMA_CLOCK() 0ll
