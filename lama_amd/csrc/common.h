@@ -104,6 +104,15 @@ __device__ __forceinline__ lama_buf_t lama_make_buf(const void* ptr, long long b
 // v_fma_mixlo_f16 / v_fma_mixhi_f16 form the fp32 residual (exact: |x - fp16(x)| <= half an fp16 ulp of x = at most 13 significant bits) and round it to
 // fp16 INTO the low / high half of the destination, keeping its other half -- the residual + v_cvt_pk_f16_f32 of the three-instruction form in one.  Same
 // bits: the intermediate fp32 residual is exact, so one rounding (RNE) either way.  (tests/hipemu overrides it for the host build.)
+// Halo differences of the Winograd staging transform inside a 16-lane DPP row (wino_dev.inc, GEO 1): the subtraction itself carries the DPP operand, and the
+// row's edge lane (no source lane) keeps the destination's previous value -- the caller's 0 = the difference with the reflected column.
+//   LAMA_ROW_SHR1_SUB(d, s, b):  d = s[lane - 1] - b   (lanes 1 .. 15 of a row; lane 0: d = 0)
+//   LAMA_ROW_SHL1_RSUB(d, s, b): d = b - s[lane + 1]   (lanes 0 .. 14 of a row; lane 15: d = 0)
+// Two VALU instructions (v_mov d, 0 + v_sub / v_subrev_f32_dpp) instead of three (v_mov old + v_mov_b32_dpp + v_sub).  (tests/hipemu overrides them.)
+#ifndef LAMA_ROW_SHR1_SUB
+#define LAMA_ROW_SHR1_SUB(d, s, b) do { (d) = 0.0f; asm("v_sub_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(b)); } while (0)
+#define LAMA_ROW_SHL1_RSUB(d, s, b) do { (d) = 0.0f; asm("v_subrev_f32_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(b)); } while (0)
+#endif
 #ifndef LAMA_F16_SPLIT_LO
 #define LAMA_F16_SPLIT_LO(lo, packed, a, b)                                                                                         \
     do {                                                                                                                            \

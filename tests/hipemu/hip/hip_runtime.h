@@ -150,7 +150,10 @@ static inline T hipemu_update_dpp(T oldv, T src, int ctrl, int row_mask, int ban
     memcpy(mine, &src, 4);
     auto all = hipemu::exchange(mine, 1);
     const int l = hipemu::lane();
-    const int from = ctrl == 0x138 ? l - 1 : (ctrl == 0x130 ? l + 1 : -2);
+    // wave_shr:1 / wave_shl:1 (whole wave) and row_shr:1 / row_shl:1 (inside the 16-lane row: the row's first / last lane has no source)
+    int from = ctrl == 0x138 ? l - 1 : (ctrl == 0x130 ? l + 1 : -2);
+    if (ctrl == 0x111) from = (l & 15) == 0 ? -1 : l - 1;
+    if (ctrl == 0x101) from = (l & 15) == 15 ? -1 : l + 1;
     if (from == -2) { std::fprintf(stderr, "hipemu: dpp ctrl 0x%x not emulated\n", ctrl); std::abort(); }
     (void)row_mask; (void)bank_mask;
     if (from < 0 || from > 63) return bound_ctrl ? T(0) : oldv;
@@ -350,6 +353,9 @@ static inline unsigned hipemu_f16_split_lo(unsigned packed, float a, float b) { 
     return (unsigned)u0 | ((unsigned)u1 << 16);
 }
 #define LAMA_F16_SPLIT_LO(lo, packed, a, b) ((lo) = hipemu_f16_split_lo(packed, a, b))
+// v_sub_f32_dpp row_shr:1 / v_subrev_f32_dpp row_shl:1 with a zeroed destination (the row's edge lane keeps 0)
+#define LAMA_ROW_SHR1_SUB(d, s, b) do { const bool e_ = (hipemu::lane() & 15) == 0; const float t_ = hipemu_update_dpp(0.0f, (float)(s), 0x111, 0xf, 0xf, false); (d) = e_ ? 0.0f : t_ - (b); } while (0)
+#define LAMA_ROW_SHL1_RSUB(d, s, b) do { const bool e_ = (hipemu::lane() & 15) == 15; const float t_ = hipemu_update_dpp(0.0f, (float)(s), 0x101, 0xf, 0xf, false); (d) = e_ ? 0.0f : (b) - t_; } while (0)
 #define LAMA_WAVE_UNIFORM(x) (x)
 #define LAMA_WAVE_SYNC() hipemu::wave_barrier()
 #define LAMA_CLOCK() 0ll
