@@ -337,6 +337,14 @@ static inline void hipemu_buf_store_b64(lama_buf_t r, hipemu_u32x2 v, unsigned v
 #define LAMA_BUF_RSRC(ptr, bytes) lama_buf_t{(const char*)(ptr), (unsigned long long)(unsigned)(bytes)}
 #define LAMA_BUF_LOAD_B32(rsrc, voff, soff) hipemu_buf_load_b32(rsrc, voff, soff)
 #define LAMA_BUF_LOAD_B128(rsrc, voff, soff) hipemu_buf_load_b128(rsrc, voff, soff)
+// v_perm_b32: byte k of the result = byte sel[k] of the 8 bytes {s0 (4..7), s1 (0..3)}  (selector values 0..7 only: what the kernels use)
+static inline unsigned hipemu_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long v = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) r |= (unsigned)((v >> (8 * ((sel >> (8 * k)) & 7))) & 0xff) << (8 * k);
+    return r;
+}
+#define __builtin_amdgcn_perm(s0, s1, sel) hipemu_perm(s0, s1, sel)
 static inline float hipemu_f16_residual(unsigned packed, float x, int hi) {
     unsigned short b = (unsigned short)(hi ? packed >> 16 : packed & 0xffffu);
     _Float16 h;
