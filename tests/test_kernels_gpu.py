@@ -260,6 +260,32 @@ def test_rfft2_irfft2_every_length_up_to_256(lib):
     print('worst', worst)
 
 
+def test_winograd_rows16_staging_is_bit_identical(lib_forced, monkeypatch):
+    """GEO 1 of wino_gemm_kernel (64-column planes: halo columns by row DPP inside the 16-lane row that is the tile row, halo differences from
+    v_sub_f32_dpp -- round 6, fourth session) against the any-geometry staging of the same kernel (LAMA_WG_GEO=0 in the profiling build): the same
+    arithmetic on the same values in the same order, so the partial sums and the output are equal bit for bit -- edge tiles (reflected columns 1 and
+    W - 2) included, for the bottleneck's shape and a ragged batch."""
+    lib = lib_forced
+    st = torch.cuda.current_stream().cuda_stream
+    for B, cin, cout, H in ((8, 512, 128, 64), (3, 64, 256, 16)):
+        g = torch.Generator().manual_seed(B * 100 + H)
+        x = torch.randn(B, cin, H, 64, generator=g).to(DEV)
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.03).to(DEV)
+        bias, resid = torch.randn(cout, generator=g).to(DEV), torch.randn(B, cout, H, 64, generator=g).to(DEV)
+        wp = lib.pack_winograd_weight(w, None, L.PREC_F16X3)
+        outs = []
+        for geo in ('0', '1'):
+            monkeypatch.setenv('LAMA_WG_GEO', geo)
+            ws = torch.zeros(lib.winograd_workspace_bytes(B, cout, H, 64) // 4, device=DEV)
+            y = torch.zeros(B, cout, H, 64, device=DEV)
+            lib.winograd_conv3x3(L.view(x), wp, L.view(y), B, ws, bias, L.ACT_RELU, L.view(resid), precision=L.PREC_F16X3, stream=st)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), ws.clone()))
+        assert torch.equal(outs[0][1], outs[1][1]), 'partial sums differ'
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert float(outs[1][0].abs().max()) > 0
+
+
 def test_fft_masked_entries(lib):
     """lama_rfft2_masked_fwd / lama_irfft2_masked_fwd (v108) on 256 x 256 planes against transform + separate mask, channel views of wider buffers."""
     g = torch.Generator().manual_seed(77)
